@@ -1,0 +1,423 @@
+"""Host-side mirror of the reference's interface for the hot path.
+
+Names, argument meaning and error behaviour follow CausalGPSLC.jl so that the parity tests read
+like the reference's own tests:
+
+    rbfKernelLog, processCov                      src/kernel.jl:24-32, 53-59
+    GPSLCObject (data + flattened posterior)      src/types.jl:249-258, src/utils.jl:92-124
+    conditionalITE, ITEDistributions, ITEsamples,
+    conditionalSATE, SATEDistributions, SATEsamples   src/estimation.jl:36-163
+    sampleITE, sampleSATE, summarizeEstimates     src/driver.jl:86-89, 108-111, 129-149
+    predictCounterfactualEffects                  src/prediction.jl:23-36
+    yLogpdf                                       src/model_likelihood.jl:83-120 (:Y node score)
+
+Everything numeric is done by libgpslc_hip.so through the C ABI (``_lib``); this module only
+marshals arrays (NumPy, column-major) and reproduces the reference's output layouts.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import GPSLCError, PosDefException
+
+PREDICTION_COVARIANCE_NOISE = 1e-10   # src/hyperparameters.jl:92
+
+
+def _f(a, shape=None):
+    """float64, column-major, contiguous."""
+    a = np.asarray(a)
+    if a.dtype == np.bool_:
+        a = a.astype(np.float64)
+    a = np.asfortranarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise AssertionError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """RAII wrapper of gpslc_ctx (one per GPU and data set)."""
+
+    def __init__(self, n, nX, nU, device=0, profile=False):
+        self.lib = _lib.load()
+        self.n, self.nX, self.nU = int(n), int(nX), int(nU)
+        h = C.c_void_p()
+        st = self.lib.gpslc_create(C.byref(h), int(device), self.n, self.nX, self.nU, 1 if profile else 0)
+        if st != 0:
+            raise GPSLCError(st, {-1003: "no usable gfx950 device"}.get(st, "gpslc_create failed"))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gpslc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, st):
+        if st < 0:
+            raise GPSLCError(st, self.lib.gpslc_last_error(self.h).decode())
+        if st > 0:
+            raise PosDefException(st)
+
+    def set_data(self, X, T, Y):
+        X = None if self.nX == 0 else _f(X).reshape(self.n, self.nX, order="F")
+        T = _f(T, (self.n,))
+        Y = _f(Y, (self.n,))
+        self._keep = (X, T, Y)
+        self.check(self.lib.gpslc_set_data(self.h, _p(X), _p(T), _p(Y)))
+
+    def set_tuning(self, max_batch=0, panel_tiles=0, n_streams=0):
+        self.check(self.lib.gpslc_set_tuning(self.h, max_batch, panel_tiles, n_streams))
+
+    def last_info(self, S):
+        out = np.zeros(S, dtype=np.int32)
+        self.check(self.lib.gpslc_last_info(self.h, out.ctypes.data_as(_lib.c_int32_p), S))
+        return out
+
+    def profile_reset(self):
+        self.lib.gpslc_profile_reset(self.h)
+
+    def profile_get(self):
+        n = C.c_int64()
+        ms = C.c_double()
+        fl = C.c_double()
+        self.lib.gpslc_profile_get(self.h, C.byref(n), C.byref(ms), C.byref(fl))
+        return n.value, ms.value, fl.value
+
+
+_scratch_ctx: Optional[Context] = None
+
+
+def _kernel_ctx() -> Context:
+    global _scratch_ctx
+    if _scratch_ctx is None:
+        _scratch_ctx = Context(1, 0, 0)
+    return _scratch_ctx
+
+
+# ------------------------------------------------------------------------------------------
+# src/kernel.jl
+# ------------------------------------------------------------------------------------------
+
+def rbfKernelLog(X1, X2, LS):
+    """rbfKernelLog(X1, X2, LS) -> n x n (src/kernel.jl:24-32 matrix/vector; :34-42 vector of vectors)."""
+    A = np.asarray(X1)
+    B = np.asarray(X2)
+    if A.dtype == object or B.dtype == object:
+        raise TypeError("ragged input")
+    if A.shape != B.shape:
+        raise AssertionError("X1 and X2 are different sizes!")
+    A = _f(A if A.ndim == 2 else A.reshape(A.shape[0], -1))
+    B = _f(B if B.ndim == 2 else B.reshape(B.shape[0], -1))
+    n, d = A.shape
+    ls = np.atleast_1d(np.asarray(LS, dtype=np.float64))
+    if ls.shape[0] not in (1, d) or ls.ndim != 1:
+        raise AssertionError("vector lengthscale doesn't match individual")
+    ls = np.ascontiguousarray(ls)
+    out = np.empty((n, n), order="F")
+    ctx = _kernel_ctx()
+    ctx.check(ctx.lib.gpslc_rbf_log(ctx.h, _p(A), _p(B), n, d, _p(ls), ls.shape[0], _p(out)))
+    return out
+
+
+def processCov(logCov, scale, noise=None):
+    """processCov(logCov, scale[, noise]) (src/kernel.jl:53-59)."""
+    lc = _f(np.atleast_2d(logCov))
+    n = lc.shape[0]
+    if lc.shape != (n, n):
+        raise AssertionError("logCov must be square")
+    out = np.empty((n, n), order="F")
+    ctx = _kernel_ctx()
+    ctx.check(ctx.lib.gpslc_process_cov(ctx.h, _p(lc), n, float(scale), 0.0 if noise is None else float(noise),
+                                        _p(out)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# GPSLCObject: data + the flattened posterior pack extractParameters would produce
+# ------------------------------------------------------------------------------------------
+
+@dataclass
+class HyperParameters:
+    """src/types.jl:22-30 with the defaults of src/hyperparameters.jl:85-102."""
+    nU: Optional[int] = 1
+    nOuter: int = 24
+    nMHInner: int = 10
+    nESInner: int = 5
+    nBurnIn: int = 10
+    stepSize: int = 1
+    predictionCovarianceNoise: float = PREDICTION_COVARIANCE_NOISE
+
+
+@dataclass
+class GPSLCObject:
+    """Data (X, T, Y) plus the posterior samples in flat form.
+
+    ``U`` (n, nU, S), ``uyLS`` (nU, S), ``xyLS`` (nX, S), ``tyLS``/``yNoise``/``yScale`` (S,) are the
+    values ``extractParameters(g, i)`` (src/utils.jl:92-124) returns for i in nBurnIn:stepSize:nOuter
+    (burn-in index inclusive, src/estimation.jl:72,78), stacked along the last axis.  ``U``/``uyLS``
+    are None for the models without latent confounders, ``X``/``xyLS`` None without covariates.
+    """
+    X: Optional[np.ndarray]
+    T: np.ndarray
+    Y: np.ndarray
+    U: Optional[np.ndarray]
+    uyLS: Optional[np.ndarray]
+    xyLS: Optional[np.ndarray]
+    tyLS: np.ndarray
+    yNoise: np.ndarray
+    yScale: np.ndarray
+    hyperparams: HyperParameters = field(default_factory=HyperParameters)
+    device: int = 0
+    _ctx: Optional[Context] = field(default=None, repr=False)
+
+    def __post_init__(self):
+        self.T = _f(self.T).reshape(-1)
+        self.Y = _f(self.Y).reshape(-1)
+        n = self.Y.shape[0]
+        if self.T.shape[0] != n:
+            raise AssertionError("size(T, 1) != n")
+        if self.X is not None:
+            self.X = _f(self.X).reshape(n, -1, order="F")
+        self.tyLS = np.ascontiguousarray(np.atleast_1d(self.tyLS), dtype=np.float64)
+        S = self.tyLS.shape[0]
+        self.yNoise = np.ascontiguousarray(np.atleast_1d(self.yNoise), dtype=np.float64)
+        self.yScale = np.ascontiguousarray(np.atleast_1d(self.yScale), dtype=np.float64)
+        if self.U is not None:
+            U = np.asarray(self.U, dtype=np.float64)
+            if U.ndim == 2:
+                U = U[:, :, None] if S == 1 else U[:, None, :]
+            self.U = np.asfortranarray(U)
+            if self.U.shape[0] != n or self.U.shape[2] != S:
+                raise AssertionError("size(U, 1) != n")
+            self.uyLS = np.asfortranarray(np.asarray(self.uyLS, dtype=np.float64).reshape(self.U.shape[1], S, order="F"))
+        if self.X is not None:
+            self.xyLS = np.asfortranarray(np.asarray(self.xyLS, dtype=np.float64).reshape(self.X.shape[1], S, order="F"))
+
+    # ---- size getters, src/utils.jl:130-161
+    def getN(self):
+        return self.Y.shape[0]
+
+    def getNX(self):
+        return 0 if self.X is None else self.X.shape[1]
+
+    def getNU(self):
+        return 0 if self.U is None else self.U.shape[1]
+
+    def getNumPosteriorSamples(self):
+        return self.tyLS.shape[0]
+
+    def ctx(self) -> Context:
+        if self._ctx is None:
+            c = Context(self.getN(), self.getNX(), self.getNU(), device=self.device)
+            c.set_data(self.X, self.T, self.Y)
+            self._ctx = c
+        return self._ctx
+
+    def _params(self):
+        return (_p(self.U), _p(self.uyLS), _p(self.xyLS), _p(self.tyLS), _p(self.yScale), _p(self.yNoise))
+
+
+def getN(g):
+    return g.getN()
+
+
+def getNX(g):
+    return g.getNX()
+
+
+def getNU(g):
+    return g.getNU()
+
+
+def getNumPosteriorSamples(g):
+    return g.getNumPosteriorSamples()
+
+
+def _single(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y) -> GPSLCObject:
+    if U is not None:
+        U = np.asarray(U, dtype=np.float64)
+        U = U.reshape(U.shape[0], -1)[:, :, None]
+        uyLS = np.atleast_1d(np.asarray(uyLS, dtype=np.float64))[:, None]
+    if X is not None:
+        X = np.asarray(X, dtype=np.float64)
+        X = X.reshape(X.shape[0], -1)
+        xyLS = np.atleast_1d(np.asarray(xyLS, dtype=np.float64))[:, None]
+    return GPSLCObject(X, T, Y, U, uyLS, xyLS, [tyLS], [yNoise], [yScale])
+
+
+# ------------------------------------------------------------------------------------------
+# src/estimation.jl
+# ------------------------------------------------------------------------------------------
+
+def conditionalITE(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y, doT):
+    """conditionalITE(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y, doT) -> MeanITE (n,), CovITE (n, n)
+    (src/estimation.jl:36-50; no jitter, like the reference)."""
+    g = _single(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y)
+    M, Cv = _ite_distributions(g, doT, 0.0)
+    return M[0], Cv[0]
+
+
+def _ite_distributions(g: GPSLCObject, doT, pred_noise, want_cov=True):
+    n, S = g.getN(), g.getNumPosteriorSamples()
+    ctx = g.ctx()
+    M = np.empty((S, n), order="F")
+    Cv = np.empty((S, n, n), order="F") if want_cov else None
+    st = ctx.lib.gpslc_ite_distributions(ctx.h, S, *g._params(), float(doT), float(pred_noise), _p(M), _p(Cv))
+    ctx.check(st)
+    return M, Cv
+
+
+def ITEDistributions(g: GPSLCObject, doT):
+    """MeanITEs (S, n), CovITEs (S, n, n) incl. + I*predictionCovarianceNoise (src/estimation.jl:66-86)."""
+    return _ite_distributions(g, doT, g.hyperparams.predictionCovarianceNoise)
+
+
+def conditionalSATE(MeanITE, CovITE):
+    """src/estimation.jl:116-121 (pure reduction; kept on the host for API parity)."""
+    n = MeanITE.shape[0]
+    return float(np.sum(MeanITE) / n), float(np.sum(CovITE) / n ** 2)
+
+
+def SATEDistributions(g: GPSLCObject, doT):
+    """MeanSATEs (S,), VarSATEs (S,) (src/estimation.jl:127-140) — O(N^2) per sample on the GPU,
+    without materialising CovITE."""
+    m, v, _ = predict(g, [doT])
+    return m[:, 0].copy(), v[:, 0].copy()
+
+
+def SATEsamples(MeanSATEs, VarSATEs, nSamplesPerMixture, z=None, seed=0):
+    """src/estimation.jl:148-163 (variance passed as sigma, :159)."""
+    lib = _lib.load()
+    m = np.ascontiguousarray(MeanSATEs, dtype=np.float64)
+    v = np.ascontiguousarray(VarSATEs, dtype=np.float64)
+    S = m.shape[0]
+    out = np.empty(S * nSamplesPerMixture)
+    zz = None if z is None else np.ascontiguousarray(z, dtype=np.float64)
+    st = lib.gpslc_sate_samples(_p(m), _p(v), S, int(nSamplesPerMixture), int(seed), _p(zz), _p(out))
+    if st != 0:
+        raise GPSLCError(st, "gpslc_sate_samples")
+    return out
+
+
+def predict(g: GPSLCObject, doTs: Sequence[float], want_mean_ite=False, spp=0, z=None, seed=0,
+            want_draws=False):
+    """The ensemble entry point (gpslc_predict): returns MeanSATE (S, L), VarSATE (S, L) and, when
+    asked, MeanITE (n, S, L) / draws (L, n, S*spp)."""
+    n, S = g.getN(), g.getNumPosteriorSamples()
+    doTs = np.ascontiguousarray(np.atleast_1d(np.asarray(doTs, dtype=np.float64)))
+    L = doTs.shape[0]
+    ctx = g.ctx()
+    ms = np.empty((S, L), order="F")
+    vs = np.empty((S, L), order="F")
+    mi = np.empty((n, S, L), order="F") if want_mean_ite else None
+    dr = np.empty((L, n, S * spp), order="F") if want_draws else None
+    zz = None
+    if z is not None:
+        zz = _f(z)
+        if zz.shape != (n, spp, S, L):
+            raise AssertionError(f"z must be (n, spp, S, L) = {(n, spp, S, L)}, got {zz.shape}")
+    st = ctx.lib.gpslc_predict(ctx.h, S, *g._params(), L, _p(doTs), float(g.hyperparams.predictionCovarianceNoise),
+                               int(spp), int(seed), _p(zz), _p(ms), _p(vs), _p(mi), _p(dr))
+    ctx.check(st)
+    if want_draws:
+        return ms, vs, mi, dr
+    return ms, vs, mi
+
+
+def ITEsamples(g_or_means, doT_or_covs, nSamplesPerMixture, z=None, seed=0):
+    """ITEsamples: n x (S*spp) draws, column order sample-outer / draw-inner (src/estimation.jl:95-109).
+    Called as ITEsamples(g, doT, spp): the factor of CovITE + jitter is computed once per sample on the GPU."""
+    g, doT = g_or_means, doT_or_covs
+    zz = None
+    if z is not None:   # z given in the reference's (n, S*spp) column order
+        n, S = g.getN(), g.getNumPosteriorSamples()
+        # column j*spp + d  ->  [i, d, j] under a column-major reshape
+        zz = np.asarray(z, dtype=np.float64).reshape(n, nSamplesPerMixture, S, order="F")[:, :, :, None]
+    _, _, _, dr = predict(g, [doT], spp=nSamplesPerMixture, z=zz, seed=seed, want_draws=True)
+    return np.asfortranarray(dr[0])
+
+
+# ------------------------------------------------------------------------------------------
+# src/driver.jl, src/prediction.jl
+# ------------------------------------------------------------------------------------------
+
+def sampleITE(g: GPSLCObject, doT, samplesPerPosterior=10, z=None, seed=0):
+    """sampleITE(g, doT; samplesPerPosterior=10) -> n x (S*spp) (src/driver.jl:86-89)."""
+    return ITEsamples(g, doT, samplesPerPosterior, z=z, seed=seed)
+
+
+def sampleSATE(g: GPSLCObject, doT, samplesPerPosterior=10, z=None, seed=0):
+    """sampleSATE(g, doT; samplesPerPosterior=10) -> (S*spp,) (src/driver.jl:108-111)."""
+    m, v = SATEDistributions(g, doT)
+    return SATEsamples(m, v, samplesPerPosterior, z=z, seed=seed)
+
+
+def doTRange(minDoT, maxDoT, fidelity):
+    """``minDoT:(|maxDoT-minDoT|/fidelity):maxDoT`` (src/prediction.jl:24-28)."""
+    delta = abs(maxDoT - minDoT)
+    step = delta / fidelity
+    if step == 0:
+        raise ValueError("range step cannot be zero")
+    if maxDoT < minDoT:
+        return np.zeros(0)
+    npts = int(np.floor((maxDoT - minDoT) / step + 1e-9)) + 1
+    return minDoT + step * np.arange(npts)
+
+
+def predictCounterfactualEffects(g: GPSLCObject, nSamplesPerMixture, fidelity=100, minDoT=None, maxDoT=None,
+                                 z=None, seed=0):
+    """predictCounterfactualEffects(g, spp; fidelity, minDoT, maxDoT) -> (ite [L, n, S*spp], doTrange)
+    (src/prediction.jl:23-36).  All levels share one factorisation of A per posterior sample."""
+    lo = float(np.min(g.T)) if minDoT is None else float(minDoT)
+    hi = float(np.max(g.T)) if maxDoT is None else float(maxDoT)
+    rng = doTRange(lo, hi, fidelity)
+    zz = None
+    if z is not None:   # (L, n, S*spp) in the reference's order
+        n, S = g.getN(), g.getNumPosteriorSamples()
+        L = rng.shape[0]
+        zz = np.asarray(z, dtype=np.float64).reshape(L, n, nSamplesPerMixture, S, order="F")
+        zz = np.transpose(zz, (1, 2, 3, 0))
+    _, _, _, dr = predict(g, rng, spp=nSamplesPerMixture, z=zz, seed=seed, want_draws=True)
+    return dr, rng
+
+
+def summarizeEstimates(samples, credible_interval=0.90):
+    """Mean and credible bounds per individual (src/driver.jl:129-149; Julia's type-7 quantile).
+    Host-side: O(n*m) glue, listed as 'next-4' in SURVEY.md §8f."""
+    lo = (1 - credible_interval) / 2
+    hi = 1 - lo
+    s = np.asarray(samples, dtype=np.float64)
+    return {"Individual": np.arange(1, s.shape[0] + 1), "Mean": s.mean(axis=1),
+            "LowerBound": np.quantile(s, lo, axis=1, method="linear"),
+            "UpperBound": np.quantile(s, hi, axis=1, method="linear")}
+
+
+# ------------------------------------------------------------------------------------------
+# src/model_likelihood.jl :Y node
+# ------------------------------------------------------------------------------------------
+
+def yLogpdf(g: GPSLCObject, X_override=None):
+    """log N(Y; 0, Ycov) for every parameter set of ``g`` (the score the :Y address contributes to a
+    Gen trace; src/model_likelihood.jl:83-120)."""
+    S = g.getNumPosteriorSamples()
+    ctx = g.ctx()
+    out = np.empty(S)
+    Xo = None if X_override is None else _f(X_override).reshape(g.getN(), g.getNX(), order="F")
+    U, uy, xy, ty, ys, yn = g._params()
+    st = ctx.lib.gpslc_y_logpdf(ctx.h, S, U, _p(Xo), uy, xy, ty, ys, yn, _p(out))
+    ctx.check(st)
+    return out

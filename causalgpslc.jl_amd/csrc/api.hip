@@ -1,0 +1,763 @@
+// Host side of libgpslc_hip.so: context, workspace, chunk scheduling over HIP streams, and the
+// C ABI of include/gpslc_hip.h.  No exception crosses the ABI (everything is caught and mapped to
+// a status code); every HIP error is reported through gpslc_last_error.
+#include "../../include/gpslc_hip.h"
+#include "gpslc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct HipFail {
+    hipError_t e;
+    const char* what;
+    int line;
+};
+#define HC(x)                                                         \
+    do {                                                              \
+        hipError_t _e = (x);                                          \
+        if (_e != hipSuccess) throw HipFail{_e, #x, __LINE__};        \
+    } while (0)
+
+struct Arena {
+    char* base = nullptr;
+    size_t bytes = 0;
+    size_t off = 0;
+    void reset() { off = 0; }
+    template <class T>
+    T* take(size_t count) {
+        size_t a = (off + 255) & ~size_t(255);
+        size_t need = count * sizeof(T);
+        if (a + need > bytes) throw std::bad_alloc();
+        off = a + need;
+        return reinterpret_cast<T*>(base + a);
+    }
+};
+
+struct ProfRec {
+    hipEvent_t a, b;
+    double flop;
+};
+
+}  // namespace
+
+struct gpslc_ctx {
+    int device = 0;
+    int64_t n = 0;
+    int nX = 0, nU = 0;
+    uint32_t flags = 0;
+    int nt = 0;
+    double *dX = nullptr, *dT = nullptr, *dY = nullptr;
+    bool has_data = false;
+    int max_batch = 0;   // 0 = auto
+    int panel = 2;
+    int nstreams = 2;
+    std::vector<hipStream_t> streams;
+    std::vector<Arena> arenas;     // one per stream slot
+    Arena scratch;                 // call-level buffers (host-pointer entry points, info, ...)
+    std::string err;
+    std::vector<int32_t> last_info;
+    // profiling of the dominant kernel
+    std::vector<ProfRec> prof;
+    size_t prof_used = 0;
+    int64_t prof_launches = 0;
+    double prof_ms = 0.0, prof_flop = 0.0;
+};
+
+namespace {
+
+void set_err(gpslc_ctx* c, const std::string& s) {
+    if (c) c->err = s;
+}
+
+int fail_hip(gpslc_ctx* c, const HipFail& f) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) at api.hip:%d in `%s`", (int)f.e, hipGetErrorString(f.e),
+             f.line, f.what);
+    set_err(c, buf);
+    return GPSLC_ERR_HIP;
+}
+
+void arena_reserve(gpslc_ctx* c, Arena& a, size_t bytes) {
+    if (a.bytes >= bytes) return;
+    if (a.base) {
+        HC(hipDeviceSynchronize());
+        HC(hipFree(a.base));
+        a.base = nullptr;
+        a.bytes = 0;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        throw std::bad_alloc();
+    }
+    a.base = static_cast<char*>(p);
+    a.bytes = bytes;
+    (void)c;
+}
+
+void ensure_streams(gpslc_ctx* c) {
+    while ((int)c->streams.size() < c->nstreams) {
+        hipStream_t s;
+        HC(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        c->streams.push_back(s);
+    }
+    if ((int)c->arenas.size() < c->nstreams) c->arenas.resize(c->nstreams);
+}
+
+// ---- profiled launch of the accumulate-mode tile kernel ---------------------------------
+void gemm(gpslc_ctx* c, const GemmArgs& g, hipStream_t st) {
+    if (g.ntiles <= 0 || g.nbatch <= 0 || (g.k1 <= g.k0 && g.accumulate)) return;
+    const bool prof = (c->flags & GPSLC_FLAG_PROFILE) && g.accumulate;
+    if (prof) {
+        if (c->prof_used == c->prof.size()) {
+            ProfRec r;
+            HC(hipEventCreate(&r.a));
+            HC(hipEventCreate(&r.b));
+            r.flop = 0;
+            c->prof.push_back(r);
+        }
+        ProfRec& r = c->prof[c->prof_used++];
+        r.flop = 2.0 * GP_TS * GP_TS * GP_TS * (double)(g.k1 - g.k0) * (double)g.ntiles * (double)g.nbatch;
+        HC(hipEventRecord(r.a, st));
+        launch_tile_gemm(g, st);
+        HC(hipEventRecord(r.b, st));
+    } else {
+        launch_tile_gemm(g, st);
+    }
+}
+
+void prof_collect(gpslc_ctx* c) {
+    for (size_t i = 0; i < c->prof_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->prof[i].a, c->prof[i].b) == hipSuccess) {
+            c->prof_ms += ms;
+            c->prof_flop += c->prof[i].flop;
+            c->prof_launches += 1;
+        }
+    }
+    c->prof_used = 0;
+}
+
+TRef lower_ref(double* base, long long bstride) { return TRef{base, bstride, 0, 0, 0, 0}; }
+TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstride, 1, 0, 0, ld}; }
+
+// Blocked Cholesky of the leading nt x nt tiles of the lower-packed ntot x ntot tile matrix M; the
+// rows nt..ntot-1 are carried along (augmented rows): after the call they hold R = rows * L^-T and the
+// trailing (ntot-nt)^2 block its Schur complement.  Panels of `pw` tile columns: left-looking inside a
+// panel, one right-looking trailing update (K = pw*128) per panel.
+void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, long long inv_bstride,
+                 int* info, int info_base, int nb, hipStream_t st) {
+    const int pw = std::max(1, c->panel);
+    TRef invref = TRef{inv, inv_bstride, 1, 0, 0, 0};   // tile (j, kk) -> inv[kk]
+    for (int k = 0; k < nt; ++k) {
+        const int ka = (k / pw) * pw;
+        const int kend = std::min(ka + pw, nt);
+        if (k > ka) {   // column update inside the panel: tile(i,k) -= sum_{kk in [ka,k)} tile(i,kk) tile(k,kk)^T
+            GemmArgs g{};
+            g.A = M; g.B = M; g.C = M;
+            g.shape = 1; g.i0 = k; g.j0 = k; g.mi = ntot - k; g.mj = 1;
+            g.k0 = ka; g.k1 = k; g.accumulate = 1; g.nbatch = nb; g.ntiles = g.mi;
+            gemm(c, g, st);
+        }
+        launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
+        if (ntot - k - 1 > 0) {   // panel: tile(i,k) = tile(i,k) * inv(L_kk)^T
+            GemmArgs g{};
+            g.A = M; g.B = invref; g.C = M;
+            g.shape = 1; g.i0 = k + 1; g.j0 = k; g.mi = ntot - k - 1; g.mj = 1;
+            g.k0 = k; g.k1 = k + 1; g.accumulate = 0; g.nbatch = nb; g.ntiles = g.mi;
+            gemm(c, g, st);
+        }
+        if (k == kend - 1 && ntot - kend > 0) {   // trailing update with the whole panel
+            GemmArgs g{};
+            g.A = M; g.B = M; g.C = M;
+            const int m = ntot - kend;
+            g.shape = 0; g.i0 = kend; g.j0 = kend; g.mi = m; g.mj = m;
+            g.k0 = ka; g.k1 = kend; g.accumulate = 1; g.nbatch = nb; g.ntiles = m * (m + 1) / 2;
+            gemm(c, g, st);
+        }
+    }
+}
+
+struct PredictIO {
+    int64_t S = 0;
+    SampleParams p{};
+    const double* X = nullptr;   // device X to use (ctx or override)
+    int L = 0;
+    const double* doT = nullptr;
+    double pred_noise = 0;
+    int spp = 0;
+    uint64_t seed = 0;
+    const double* z = nullptr;
+    double *meanSATE = nullptr, *varSATE = nullptr, *meanITE = nullptr, *ite_draws = nullptr;
+    double *logdet = nullptr, *quad = nullptr;
+    // ITEDistributions-style outputs (single level): MeanITEs S x n, CovITEs S x n x n
+    double *MeanITEs = nullptr, *CovITEs = nullptr;
+    int* info = nullptr;   // device, S
+};
+
+int auto_batch(gpslc_ctx* c, int64_t S, size_t per_sample_bytes, size_t fixed_bytes) {
+    long long b = 32768LL / ((long long)c->nt * c->nt);
+    b = std::max<long long>(32, std::min<long long>(b, 4096));
+    if (c->max_batch > 0) b = c->max_batch;
+    size_t free_b = 0, tot_b = 0;
+    HC(hipMemGetInfo(&free_b, &tot_b));
+    size_t have = 0;
+    for (auto& a : c->arenas) have += a.bytes;
+    const double budget = 0.70 * ((double)free_b + (double)have) / c->nstreams - (double)fixed_bytes;
+    long long cap = (long long)(budget / (double)per_sample_bytes);
+    if (cap < 1) throw std::bad_alloc();
+    b = std::min(b, cap);
+    b = std::min<long long>(b, S);
+    return (int)std::max<long long>(1, b);
+}
+
+// the chunked ensemble driver (device pointers everywhere)
+void run_predict(gpslc_ctx* c, const PredictIO& io) {
+    ensure_streams(c);
+    const int n = (int)c->n, nt = c->nt;
+    const int L = io.L;
+    const int naug = (L + 1 + GP_TS - 1) / GP_TS;
+    const int ntot = nt + naug;
+    const long long Np = (long long)nt * GP_TS;
+    const long long tiles_per = (long long)ntot * (ntot + 1) / 2;
+    const bool want_sate = io.meanSATE || io.varSATE;
+    const bool want_cov = io.CovITEs != nullptr;
+    const bool want_draws = io.ite_draws != nullptr;
+    const bool want_mean = io.meanITE || io.MeanITEs || want_draws;
+    const bool with_sums = want_sate;
+    const long long nlow = (long long)nt * (nt + 1) / 2;
+
+    // unit-B sub-batch (full ITE covariance): W (nt^2 tiles) + Cm (nlow tiles) + inv (nt tiles)
+    const bool unitB = want_cov || want_draws;
+    const size_t unitB_per = unitB ? (size_t)((long long)nt * nt + nlow + nt) * GP_TSQ * 8 : 0;
+
+    size_t per = (size_t)tiles_per * GP_TSQ * 8      // tiles
+               + (size_t)nt * GP_TSQ * 8             // inv
+               + (size_t)(with_sums ? 2 * nt * Np * 8 : 0)
+               + (size_t)(2 * Np * 8)                // bsum, ksum
+               + (size_t)(std::max(L, 1) * 8)        // sumdelta
+               + (size_t)(2 * Np * 8)                // zwork + alpha
+               + 1024;
+    int Bb_target = 0;
+    if (unitB) {
+        // keep the unit-B sub-batch modest: it multiplies memory by ~3x per unit
+        Bb_target = (int)std::max<long long>(1, std::min<long long>(64, 16384LL / ((long long)nt * nt)));
+    }
+    const size_t fixed = (size_t)Bb_target * unitB_per + (1 << 20);
+    const int Bt = auto_batch(c, io.S, per, fixed);
+    const int Bb = unitB ? std::min(Bb_target, Bt) : 0;
+    const size_t need = (size_t)Bt * per + (size_t)Bb * unitB_per + (1 << 20);
+    for (int i = 0; i < c->nstreams; ++i) arena_reserve(c, c->arenas[i], need);
+
+    // internal MeanITE buffer when the caller did not ask for it but the draws need it
+    double* meanITE = io.meanITE;
+    if (want_draws && !meanITE) {
+        arena_reserve(c, c->scratch, std::max(c->scratch.bytes, (size_t)n * io.S * L * 8 + (1 << 16)));
+        c->scratch.reset();
+        meanITE = c->scratch.take<double>((size_t)n * io.S * L);
+    }
+
+    HC(hipMemsetAsync(io.info, 0, sizeof(int) * io.S, c->streams[0]));
+    HC(hipStreamSynchronize(c->streams[0]));
+
+    int chunk = 0;
+    for (int64_t s0 = 0; s0 < io.S; s0 += Bt, ++chunk) {
+        const int nb = (int)std::min<int64_t>(Bt, io.S - s0);
+        const int slot = chunk % c->nstreams;
+        hipStream_t st = c->streams[slot];
+        Arena& ar = c->arenas[slot];
+        ar.reset();
+        double* tiles = ar.take<double>((size_t)nb * tiles_per * GP_TSQ);
+        double* inv = ar.take<double>((size_t)nb * nt * GP_TSQ);
+        double* part = with_sums ? ar.take<double>((size_t)nb * 2 * nt * Np) : nullptr;
+        double* bsum = ar.take<double>((size_t)nb * Np);
+        double* ksum = ar.take<double>((size_t)nb * Np);
+        double* sumdelta = ar.take<double>((size_t)nb * std::max(L, 1));
+        double* zwork = ar.take<double>((size_t)2 * nb * Np);
+        const long long bstride = tiles_per * GP_TSQ;
+        const long long inv_bs = (long long)nt * GP_TSQ;
+        TRef M = lower_ref(tiles, bstride);
+
+        GramArgs ga{};
+        ga.X = io.X; ga.T = c->dT; ga.p = io.p; ga.s0 = s0;
+        ga.n = n; ga.nX = c->nX; ga.nU = c->nU; ga.nt = nt; ga.M = M; ga.part = part;
+        ga.with_sums = with_sums ? 1 : 0;
+        launch_gram(ga, nb, st);
+
+        RhsArgs ra{};
+        ra.T = c->dT; ra.Y = c->dY; ra.tyLS = io.p.tyLS; ra.doT = io.doT; ra.s0 = s0;
+        ra.n = n; ra.nt = nt; ra.naug = naug; ra.L = with_sums ? L : 0; ra.with_sums = with_sums ? 1 : 0;
+        ra.part = part; ra.bsum = bsum; ra.ksum = ksum; ra.sumdelta = sumdelta; ra.M = M;
+        launch_rhs(ra, nb, st);
+
+        potrf_tiles(c, M, nt, ntot, inv, inv_bs, io.info + s0, 0, nb, st);
+
+        EpiArgs ea{};
+        ea.M = M; ea.n = n; ea.nt = nt; ea.naug = naug; ea.L = with_sums ? L : 0; ea.s0 = s0; ea.S = io.S;
+        ea.sumdelta = sumdelta; ea.pred_noise = io.pred_noise;
+        ea.meanSATE = io.meanSATE; ea.varSATE = io.varSATE; ea.logdet = io.logdet; ea.quad = io.quad;
+        launch_epilogue(ea, nb, st);
+
+        if (want_mean) {
+            BackArgs ba{};
+            ba.M = M; ba.inv = inv; ba.inv_bstride = inv_bs; ba.nt = nt; ba.naug = naug; ba.zwork = zwork;
+            launch_backsolve(ba, nb, st);
+            const double* alpha = zwork + (long long)nb * Np;
+            IteMeanArgs ia{};
+            ia.X = io.X; ia.T = c->dT; ia.p = io.p; ia.s0 = s0; ia.S = io.S;
+            ia.n = n; ia.nX = c->nX; ia.nU = c->nU; ia.nt = nt; ia.L = L; ia.doT = io.doT; ia.alpha = alpha;
+            if (meanITE) {
+                ia.meanITE = meanITE; ia.si = 1; ia.ss = n; ia.sl = (long long)n * io.S;
+                launch_ite_mean(ia, nb, st);
+            }
+            if (io.MeanITEs) {   // reference layout S x n (single level)
+                ia.meanITE = io.MeanITEs; ia.si = io.S; ia.ss = 1; ia.sl = 0;
+                launch_ite_mean(ia, nb, st);
+            }
+        }
+
+        if (unitB) {
+            double* Wt = ar.take<double>((size_t)Bb * nt * nt * GP_TSQ);
+            double* Ct = ar.take<double>((size_t)Bb * nlow * GP_TSQ);
+            double* inv2 = ar.take<double>((size_t)Bb * nt * GP_TSQ);
+            const long long wbs = (long long)nt * nt * GP_TSQ, cbs = nlow * GP_TSQ;
+            std::vector<double> hdoT(L);
+            HC(hipMemcpyAsync(hdoT.data(), io.doT, sizeof(double) * L, hipMemcpyDeviceToHost, st));
+            HC(hipStreamSynchronize(st));
+            for (int l = 0; l < L; ++l) {
+                for (int u0 = 0; u0 < nb; u0 += Bb) {
+                    const int ub = std::min(Bb, nb - u0);
+                    TRef W = rect_ref(Wt, wbs, nt);
+                    TRef Cm = lower_ref(Ct, cbs);
+                    TRef Ls = lower_ref(tiles + (long long)u0 * bstride, bstride);
+                    DtArgs da{};
+                    da.X = io.X; da.T = c->dT; da.p = io.p; da.s0 = s0 + u0;
+                    da.n = n; da.nX = c->nX; da.nU = c->nU; da.nt = nt; da.doT = hdoT[l];
+                    da.pred_noise = io.pred_noise; da.W = W; da.Cm = Cm;
+                    launch_dt_build(da, ub, st);
+                    // W <- D L^-T (left-looking over tile columns)
+                    TRef invref = TRef{inv + (long long)u0 * inv_bs, inv_bs, 1, 0, 0, 0};
+                    for (int k = 0; k < nt; ++k) {
+                        if (k > 0) {
+                            GemmArgs g{};
+                            g.A = W; g.B = Ls; g.C = W;
+                            g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = nt; g.mj = 1;
+                            g.k0 = 0; g.k1 = k; g.accumulate = 1; g.nbatch = ub; g.ntiles = nt;
+                            gemm(c, g, st);
+                        }
+                        GemmArgs g{};
+                        g.A = W; g.B = invref; g.C = W;
+                        g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = nt; g.mj = 1;
+                        g.k0 = k; g.k1 = k + 1; g.accumulate = 0; g.nbatch = ub; g.ntiles = nt;
+                        gemm(c, g, st);
+                    }
+                    {   // CovITE (+ jitter) = Delta - W W^T, lower tiles
+                        GemmArgs g{};
+                        g.A = W; g.B = W; g.C = Cm;
+                        g.shape = 0; g.i0 = 0; g.j0 = 0; g.mi = nt; g.mj = nt;
+                        g.k0 = 0; g.k1 = nt; g.accumulate = 1; g.nbatch = ub; g.ntiles = (int)nlow;
+                        gemm(c, g, st);
+                    }
+                    if (want_cov) {
+                        GatherCovArgs gc{};
+                        gc.Cm = Cm; gc.n = n; gc.nt = nt; gc.s0 = s0 + u0; gc.S = io.S; gc.out = io.CovITEs;
+                        launch_gather_cov(gc, ub, st);
+                    }
+                    if (want_draws) {
+                        potrf_tiles(c, Cm, nt, nt, inv2, inv_bs, io.info + s0 + u0, n, ub, st);
+                        DrawArgs dr{};
+                        dr.Lc = Cm; dr.n = n; dr.nt = nt; dr.s0 = s0 + u0; dr.S = io.S; dr.l = l; dr.L = L;
+                        dr.spp = io.spp; dr.mean = meanITE; dr.z = io.z; dr.seed = io.seed; dr.out = io.ite_draws;
+                        launch_draws(dr, ub, st);
+                    }
+                }
+            }
+        }
+    }
+    for (auto st : c->streams) HC(hipStreamSynchronize(st));
+    HC(hipGetLastError());
+    if (c->flags & GPSLC_FLAG_PROFILE) prof_collect(c);
+    c->last_info.resize(io.S);
+    HC(hipMemcpy(c->last_info.data(), io.info, sizeof(int) * io.S, hipMemcpyDeviceToHost));
+}
+
+int first_info(const gpslc_ctx* c) {
+    for (int32_t v : c->last_info)
+        if (v != 0) return v;
+    return 0;
+}
+
+template <class F>
+int guarded(gpslc_ctx* c, F&& f) {
+    try {
+        if (c) HC(hipSetDevice(c->device));
+        return f();
+    } catch (const HipFail& h) {
+        return fail_hip(c, h);
+    } catch (const std::bad_alloc&) {
+        set_err(c, "device workspace allocation failed");
+        return GPSLC_ERR_NOMEM;
+    } catch (...) {
+        set_err(c, "internal error");
+        return GPSLC_ERR_INTERNAL;
+    }
+}
+
+int bad_arg(gpslc_ctx* c, int k, const char* what) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "argument #%d is invalid: %s", k, what);
+    set_err(c, buf);
+    return -k;
+}
+
+// host-side Philox (same stream definition as the device code / the oracle)
+void philox_host(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t o[4]) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+double philox_normal_host(uint64_t seed, uint64_t stream, uint64_t e) {
+    uint32_t w[4];
+    const uint64_t pair = e >> 1;
+    philox_host((uint32_t)pair, (uint32_t)(pair >> 32), (uint32_t)stream, (uint32_t)(stream >> 32),
+                (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    const uint64_t A = ((uint64_t)w[0] << 21) ^ ((uint64_t)w[1] >> 11);
+    const uint64_t B = ((uint64_t)w[2] << 21) ^ ((uint64_t)w[3] >> 11);
+    const double u1 = ((double)A + 0.5) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)B + 0.5) * (1.0 / 9007199254740992.0);
+    const double rad = std::sqrt(-2.0 * std::log(u1));
+    const double ang = 6.283185307179586476925286766559 * u2;
+    return (e & 1) ? rad * std::sin(ang) : rad * std::cos(ang);
+}
+
+struct DevBuf {   // RAII device allocation for the host-pointer entry points
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void alloc(size_t bytes) {
+        if (bytes == 0) bytes = 8;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; throw std::bad_alloc(); }
+    }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+double* up(DevBuf& b, const double* host, size_t count) {
+    b.alloc(count * sizeof(double));
+    if (count) HC(hipMemcpy(b.p, host, count * sizeof(double), hipMemcpyHostToDevice));
+    return b.as<double>();
+}
+
+int check_common(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,
+                 const double* tyLS, const double* yScale, const double* yNoise) {
+    if (!c) return -1;
+    if (!c->has_data) { set_err(c, "gpslc_set_data has not been called"); return GPSLC_ERR_NODATA; }
+    if (S < 0) return bad_arg(c, 2, "S < 0");
+    if (c->nU > 0 && S > 0 && (!U || !uyLS)) return bad_arg(c, 3, "U / uyLS must not be NULL when nU > 0");
+    if (c->nX > 0 && S > 0 && !xyLS) return bad_arg(c, 5, "xyLS must not be NULL when nX > 0");
+    if (S > 0 && (!tyLS || !yScale || !yNoise)) return bad_arg(c, 6, "tyLS / yScale / yNoise must not be NULL");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gpslc_version(void) { return "gpslc_hip 0.1 gfx950"; }
+
+int gpslc_create(gpslc_ctx** out, int device, int64_t n, int32_t nX, int32_t nU, uint32_t flags) {
+    if (!out) return -1;
+    *out = nullptr;
+    if (n < 1) return -3;
+    if (nX < 0) return -4;
+    if (nU < 0) return -5;
+    if (nX + nU > 32) return -4;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return GPSLC_ERR_NODEVICE; }
+    if (device < 0 || device >= ndev) return -2;
+    gpslc_ctx* c = new (std::nothrow) gpslc_ctx();
+    if (!c) return GPSLC_ERR_NOMEM;
+    c->device = device; c->n = n; c->nX = nX; c->nU = nU; c->flags = flags;
+    c->nt = (int)((n + GP_TS - 1) / GP_TS);
+    int rc = guarded(c, [&]() {
+        hipDeviceProp_t prop;
+        HC(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            set_err(c, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+            return GPSLC_ERR_NODEVICE;
+        }
+        HC(hipMalloc((void**)&c->dX, sizeof(double) * std::max<int64_t>(1, n * nX)));
+        HC(hipMalloc((void**)&c->dT, sizeof(double) * n));
+        HC(hipMalloc((void**)&c->dY, sizeof(double) * n));
+        ensure_streams(c);
+        return GPSLC_OK;
+    });
+    if (rc != GPSLC_OK) { gpslc_destroy(c); return rc; }
+    *out = c;
+    return GPSLC_OK;
+}
+
+int gpslc_destroy(gpslc_ctx* c) {
+    if (!c) return GPSLC_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto s : c->streams) (void)hipStreamDestroy(s);
+    for (auto& a : c->arenas) if (a.base) (void)hipFree(a.base);
+    if (c->scratch.base) (void)hipFree(c->scratch.base);
+    for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    if (c->dX) (void)hipFree(c->dX);
+    if (c->dT) (void)hipFree(c->dT);
+    if (c->dY) (void)hipFree(c->dY);
+    delete c;
+    return GPSLC_OK;
+}
+
+static int set_data_impl(gpslc_ctx* c, const double* X, const double* T, const double* Y, hipMemcpyKind kind) {
+    if (!c) return -1;
+    if (c->nX > 0 && !X) return bad_arg(c, 2, "X is NULL but nX > 0");
+    if (!T) return bad_arg(c, 3, "T is NULL");
+    if (!Y) return bad_arg(c, 4, "Y is NULL");
+    return guarded(c, [&]() {
+        if (c->nX > 0) HC(hipMemcpy(c->dX, X, sizeof(double) * c->n * c->nX, kind));
+        HC(hipMemcpy(c->dT, T, sizeof(double) * c->n, kind));
+        HC(hipMemcpy(c->dY, Y, sizeof(double) * c->n, kind));
+        c->has_data = true;
+        return GPSLC_OK;
+    });
+}
+int gpslc_set_data(gpslc_ctx* c, const double* X, const double* T, const double* Y) {
+    return set_data_impl(c, X, T, Y, hipMemcpyHostToDevice);
+}
+int gpslc_set_data_dev(gpslc_ctx* c, const double* X, const double* T, const double* Y) {
+    return set_data_impl(c, X, T, Y, hipMemcpyDeviceToDevice);
+}
+
+int gpslc_set_tuning(gpslc_ctx* c, int32_t max_batch, int32_t panel_tiles, int32_t n_streams) {
+    if (!c) return -1;
+    if (max_batch < 0) return -2;
+    if (panel_tiles < 0) return -3;
+    if (n_streams < 0 || n_streams > 8) return -4;
+    if (max_batch > 0) c->max_batch = max_batch;
+    if (panel_tiles > 0) c->panel = panel_tiles;
+    if (n_streams > 0) c->nstreams = n_streams;
+    return GPSLC_OK;
+}
+
+const char* gpslc_last_error(const gpslc_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int gpslc_rbf_log(gpslc_ctx* c, const double* X1, const double* X2, int64_t n, int32_t d, const double* ls,
+                  int32_t ls_len, double* out) {
+    if (!c) return -1;
+    if (!X1) return bad_arg(c, 2, "X1 is NULL");
+    if (!X2) return bad_arg(c, 3, "X2 is NULL");
+    if (n < 1) return bad_arg(c, 4, "n < 1");
+    if (d < 1) return bad_arg(c, 5, "d < 1");
+    if (!ls) return bad_arg(c, 6, "ls is NULL");
+    if (ls_len != 1 && ls_len != d) return bad_arg(c, 7, "vector lengthscale doesn't match individual");
+    if (!out) return bad_arg(c, 8, "out is NULL");
+    return guarded(c, [&]() {
+        ensure_streams(c);
+        DevBuf a, b, l, o;
+        double* dA = up(a, X1, (size_t)n * d);
+        double* dB = up(b, X2, (size_t)n * d);
+        double* dl = up(l, ls, (size_t)ls_len);
+        o.alloc(sizeof(double) * n * n);
+        launch_rbf_log(dA, dB, n, d, dl, ls_len, o.as<double>(), c->streams[0]);
+        HC(hipStreamSynchronize(c->streams[0]));
+        HC(hipGetLastError());
+        HC(hipMemcpy(out, o.p, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+        return GPSLC_OK;
+    });
+}
+
+int gpslc_process_cov(gpslc_ctx* c, const double* logcov, int64_t n, double scale, double noise, double* out) {
+    if (!c) return -1;
+    if (!logcov) return bad_arg(c, 2, "logcov is NULL");
+    if (n < 1) return bad_arg(c, 3, "n < 1");
+    if (!out) return bad_arg(c, 6, "out is NULL");
+    return guarded(c, [&]() {
+        ensure_streams(c);
+        DevBuf a, o;
+        double* dA = up(a, logcov, (size_t)n * n);
+        o.alloc(sizeof(double) * n * n);
+        launch_process_cov(dA, n, scale, noise, o.as<double>(), c->streams[0]);
+        HC(hipStreamSynchronize(c->streams[0]));
+        HC(hipGetLastError());
+        HC(hipMemcpy(out, o.p, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+        return GPSLC_OK;
+    });
+}
+
+int gpslc_predict_dev(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,
+                      const double* tyLS, const double* yScale, const double* yNoise, int32_t L,
+                      const double* doT, double pred_noise, int32_t spp, uint64_t seed, const double* z,
+                      double* meanSATE, double* varSATE, double* meanITE, double* ite_draws) {
+    int rc = check_common(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise);
+    if (rc) return rc;
+    if (L < 1) return bad_arg(c, 9, "L < 1");
+    if (!doT) return bad_arg(c, 10, "doT is NULL");
+    if (ite_draws && spp < 1) return bad_arg(c, 12, "spp < 1 with ite_draws requested");
+    if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
+    return guarded(c, [&]() {
+        DevBuf info;
+        info.alloc(sizeof(int) * S);
+        PredictIO io;
+        io.S = S; io.p = SampleParams{U, uyLS, xyLS, tyLS, yScale, yNoise}; io.X = c->dX;
+        io.L = L; io.doT = doT; io.pred_noise = pred_noise; io.spp = spp; io.seed = seed; io.z = z;
+        io.meanSATE = meanSATE; io.varSATE = varSATE; io.meanITE = meanITE; io.ite_draws = ite_draws;
+        io.info = info.as<int>();
+        run_predict(c, io);
+        return first_info(c);
+    });
+}
+
+int gpslc_predict(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,
+                  const double* tyLS, const double* yScale, const double* yNoise, int32_t L, const double* doT,
+                  double pred_noise, int32_t spp, uint64_t seed, const double* z, double* meanSATE,
+                  double* varSATE, double* meanITE, double* ite_draws) {
+    int rc = check_common(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise);
+    if (rc) return rc;
+    if (L < 1) return bad_arg(c, 9, "L < 1");
+    if (!doT) return bad_arg(c, 10, "doT is NULL");
+    if (ite_draws && spp < 1) return bad_arg(c, 12, "spp < 1 with ite_draws requested");
+    if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
+    return guarded(c, [&]() {
+        const size_t n = (size_t)c->n;
+        DevBuf bU, buy, bxy, bty, bys, byn, bdo, bz, oms, ovs, omi, odr;
+        const double* dU = c->nU ? up(bU, U, n * c->nU * S) : nullptr;
+        const double* duy = c->nU ? up(buy, uyLS, (size_t)c->nU * S) : nullptr;
+        const double* dxy = c->nX ? up(bxy, xyLS, (size_t)c->nX * S) : nullptr;
+        const double* dty = up(bty, tyLS, S);
+        const double* dys = up(bys, yScale, S);
+        const double* dyn = up(byn, yNoise, S);
+        const double* ddo = up(bdo, doT, L);
+        const double* dz = (z && ite_draws) ? up(bz, z, n * spp * S * L) : nullptr;
+        if (meanSATE) oms.alloc(sizeof(double) * S * L);
+        if (varSATE) ovs.alloc(sizeof(double) * S * L);
+        if (meanITE) omi.alloc(sizeof(double) * n * S * L);
+        if (ite_draws) odr.alloc(sizeof(double) * (size_t)L * n * S * spp);
+        int st = gpslc_predict_dev(c, S, dU, duy, dxy, dty, dys, dyn, L, ddo, pred_noise, spp, seed, dz,
+                                   oms.as<double>(), ovs.as<double>(), omi.as<double>(), odr.as<double>());
+        if (st < 0) return st;
+        if (meanSATE) HC(hipMemcpy(meanSATE, oms.p, sizeof(double) * S * L, hipMemcpyDeviceToHost));
+        if (varSATE) HC(hipMemcpy(varSATE, ovs.p, sizeof(double) * S * L, hipMemcpyDeviceToHost));
+        if (meanITE) HC(hipMemcpy(meanITE, omi.p, sizeof(double) * n * S * L, hipMemcpyDeviceToHost));
+        if (ite_draws) HC(hipMemcpy(ite_draws, odr.p, sizeof(double) * (size_t)L * n * S * spp, hipMemcpyDeviceToHost));
+        return st;
+    });
+}
+
+int gpslc_ite_distributions(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,
+                            const double* tyLS, const double* yScale, const double* yNoise, double doT,
+                            double pred_noise, double* MeanITEs, double* CovITEs) {
+    int rc = check_common(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise);
+    if (rc) return rc;
+    if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
+    return guarded(c, [&]() {
+        const size_t n = (size_t)c->n;
+        DevBuf bU, buy, bxy, bty, bys, byn, bdo, om, oc, info;
+        const double* dU = c->nU ? up(bU, U, n * c->nU * S) : nullptr;
+        const double* duy = c->nU ? up(buy, uyLS, (size_t)c->nU * S) : nullptr;
+        const double* dxy = c->nX ? up(bxy, xyLS, (size_t)c->nX * S) : nullptr;
+        const double* dty = up(bty, tyLS, S);
+        const double* dys = up(bys, yScale, S);
+        const double* dyn = up(byn, yNoise, S);
+        const double* ddo = up(bdo, &doT, 1);
+        if (MeanITEs) om.alloc(sizeof(double) * S * n);
+        if (CovITEs) oc.alloc(sizeof(double) * S * n * n);
+        info.alloc(sizeof(int) * S);
+        PredictIO io;
+        io.S = S; io.p = SampleParams{dU, duy, dxy, dty, dys, dyn}; io.X = c->dX;
+        io.L = 1; io.doT = ddo; io.pred_noise = pred_noise;
+        io.MeanITEs = om.as<double>(); io.CovITEs = oc.as<double>(); io.info = info.as<int>();
+        run_predict(c, io);
+        if (MeanITEs) HC(hipMemcpy(MeanITEs, om.p, sizeof(double) * S * n, hipMemcpyDeviceToHost));
+        if (CovITEs) HC(hipMemcpy(CovITEs, oc.p, sizeof(double) * S * n * n, hipMemcpyDeviceToHost));
+        return first_info(c);
+    });
+}
+
+int gpslc_y_logpdf(gpslc_ctx* c, int64_t S, const double* U, const double* X_or_null, const double* uyLS,
+                   const double* xyLS, const double* tyLS, const double* yScale, const double* yNoise,
+                   double* logpdf) {
+    int rc = check_common(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise);
+    if (rc) return rc;
+    if (!logpdf) return bad_arg(c, 10, "logpdf is NULL");
+    if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
+    return guarded(c, [&]() {
+        const size_t n = (size_t)c->n;
+        DevBuf bU, bX, buy, bxy, bty, bys, byn, bdo, old, oq, info;
+        const double* dU = c->nU ? up(bU, U, n * c->nU * S) : nullptr;
+        const double* dX = (X_or_null && c->nX) ? up(bX, X_or_null, n * c->nX) : c->dX;
+        const double* duy = c->nU ? up(buy, uyLS, (size_t)c->nU * S) : nullptr;
+        const double* dxy = c->nX ? up(bxy, xyLS, (size_t)c->nX * S) : nullptr;
+        const double* dty = up(bty, tyLS, S);
+        const double* dys = up(bys, yScale, S);
+        const double* dyn = up(byn, yNoise, S);
+        const double zero = 0.0;
+        const double* ddo = up(bdo, &zero, 1);
+        old.alloc(sizeof(double) * S);
+        oq.alloc(sizeof(double) * S);
+        info.alloc(sizeof(int) * S);
+        PredictIO io;
+        io.S = S; io.p = SampleParams{dU, duy, dxy, dty, dys, dyn}; io.X = dX;
+        io.L = 0; io.doT = ddo; io.logdet = old.as<double>(); io.quad = oq.as<double>(); io.info = info.as<int>();
+        run_predict(c, io);
+        std::vector<double> ld(S), q(S);
+        HC(hipMemcpy(ld.data(), old.p, sizeof(double) * S, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(q.data(), oq.p, sizeof(double) * S, hipMemcpyDeviceToHost));
+        const double l2pi = 1.8378770664093454835606594728112;
+        for (int64_t s = 0; s < S; ++s) logpdf[s] = -0.5 * ((double)c->n * l2pi + ld[s] + q[s]);
+        return first_info(c);
+    });
+}
+
+int gpslc_sate_samples(const double* meanSATE, const double* varSATE, int64_t S, int32_t spp, uint64_t seed,
+                       const double* z, double* out) {
+    if (!meanSATE) return -1;
+    if (!varSATE) return -2;
+    if (S < 0) return -3;
+    if (spp < 0) return -4;
+    if (!out) return -7;
+    for (int64_t j = 0; j < S; ++j)
+        for (int32_t d = 0; d < spp; ++d) {
+            const int64_t i = j * spp + d;
+            const double zz = z ? z[i] : philox_normal_host(seed, (1ull << 40) + (uint64_t)j, (uint64_t)d);
+            out[i] = meanSATE[j] + varSATE[j] * zz;   // variance used as sigma: src/estimation.jl:159
+        }
+    return GPSLC_OK;
+}
+
+int gpslc_last_info(const gpslc_ctx* c, int32_t* info, int64_t S) {
+    if (!c) return -1;
+    if (!info) return -2;
+    if (S != (int64_t)c->last_info.size()) return -3;
+    if (S) memcpy(info, c->last_info.data(), sizeof(int32_t) * S);
+    return GPSLC_OK;
+}
+
+int gpslc_profile_reset(gpslc_ctx* c) {
+    if (!c) return -1;
+    c->prof_launches = 0; c->prof_ms = 0; c->prof_flop = 0; c->prof_used = 0;
+    return GPSLC_OK;
+}
+int gpslc_profile_get(gpslc_ctx* c, int64_t* launches, double* total_ms, double* total_flop) {
+    if (!c) return -1;
+    if (launches) *launches = c->prof_launches;
+    if (total_ms) *total_ms = c->prof_ms;
+    if (total_flop) *total_flop = c->prof_flop;
+    return GPSLC_OK;
+}
+
+}  // extern "C"

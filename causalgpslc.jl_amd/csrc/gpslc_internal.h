@@ -1,0 +1,129 @@
+// Internal declarations shared by the HIP translation units of libgpslc_hip.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---------------------------------------------------------------------------------------
+// Tiled storage.  Every dense matrix the factorisation touches lives in HBM as 128 x 128
+// fp64 tiles (128 KiB, column-major inside the tile: element (r, c) at c*128 + r), so a
+// K-slab of a tile is one contiguous run and every global access is a full-line stream.
+// A "tile matrix" is addressed through a TRef: lower-packed (tile (i, j), j <= i, at
+// i(i+1)/2 + j) or rectangular (i*ld + j).
+// ---------------------------------------------------------------------------------------
+#define GP_TS 128
+#define GP_TSQ (GP_TS * GP_TS)
+
+struct TRef {
+    double* base;        // first tile of batch element 0
+    long long bstride;   // doubles between consecutive batch elements
+    int kind;            // 0 = lower packed, 1 = rectangular
+    int ro, co;          // tile offsets added to (i, j)
+    int ld;              // tiles per tile-row (rectangular)
+};
+
+__host__ __device__ inline long long tref_index(const TRef& t, int i, int j) {
+    long long ii = (long long)i + t.ro, jj = (long long)j + t.co;
+    return t.kind == 0 ? ii * (ii + 1) / 2 + jj : ii * (long long)t.ld + jj;
+}
+__host__ __device__ inline double* tref_tile(const TRef& t, long long b, int i, int j) {
+    return t.base + b * t.bstride + tref_index(t, i, j) * (long long)GP_TSQ;
+}
+
+// C(i, j) (-)= sum_{kk in [k0, k1)} A(i, kk) * B(j, kk)^T over a set of output tiles.
+struct GemmArgs {
+    TRef A, B, C;
+    int shape;        // 0: lower triangle (incl. diagonal) of an mi x mi tile square, 1: mi x mj rectangle
+    int i0, j0;       // output tile (i, j) = (i0 + ii, j0 + jj)
+    int mi, mj;
+    int k0, k1;
+    int accumulate;   // 1: C -= A B^T, 0: C = A B^T
+    int nbatch;
+    int ntiles;       // output tiles per batch element
+};
+
+// per-posterior-sample inputs of the Gram build (device pointers, already offset to sample 0 of the call)
+struct SampleParams {
+    const double* U;       // n x nU x S
+    const double* uyLS;    // nU x S
+    const double* xyLS;    // nX x S
+    const double* tyLS;    // S
+    const double* yScale;  // S
+    const double* yNoise;  // S
+};
+
+struct GramArgs {
+    const double* X;   // n x nX (ctx or override)
+    const double* T;   // n
+    SampleParams p;
+    long long s0;      // first sample of this chunk
+    int n, nX, nU, nt;
+    TRef M;            // lower-packed tile matrix of the chunk
+    double* part;      // [b][2][nt][Np] partial column sums of B (0) and K (1)
+    int with_sums;
+};
+
+// launchers (implemented in the k_*.hip files); all asynchronous on `st`
+void launch_tile_gemm(const GemmArgs& g, hipStream_t st);
+void launch_diag(const TRef& M, int k, double* inv, long long inv_bstride, int* info,
+                 int info_base, int nbatch, hipStream_t st);
+void launch_gram(const GramArgs& g, int nbatch, hipStream_t st);
+
+struct RhsArgs {
+    const double* T; const double* Y; const double* tyLS; const double* doT;
+    long long s0; int n, nt, naug, L; int with_sums;
+    const double* part; double* bsum; double* ksum; double* sumdelta;  // bsum/ksum [b][Np], sumdelta [b][L]
+    TRef M;
+};
+void launch_rhs(const RhsArgs& r, int nbatch, hipStream_t st);
+
+struct EpiArgs {
+    TRef M; int n, nt, naug, L; long long s0; long long S;
+    const double* sumdelta; double pred_noise;
+    double* meanSATE; double* varSATE;   // S x L or null
+    double* logdet; double* quad;        // S or null
+};
+void launch_epilogue(const EpiArgs& e, int nbatch, hipStream_t st);
+
+struct BackArgs {
+    TRef M; const double* inv; long long inv_bstride; int nt; int naug;
+    double* zwork;   // [b][Np] in: z (copied from the augmented row), out: alpha
+};
+void launch_backsolve(const BackArgs& a, int nbatch, hipStream_t st);
+
+struct IteMeanArgs {
+    const double* X; const double* T; SampleParams p; long long s0; long long S;
+    int n, nX, nU, nt, L; const double* doT;
+    const double* alpha;   // [b][Np]
+    double* meanITE;       // element (i, s, l) at i*si + s*ss + l*sl
+    long long si, ss, sl;
+};
+void launch_ite_mean(const IteMeanArgs& a, int nbatch, hipStream_t st);
+
+void launch_rbf_log(const double* X1, const double* X2, long long n, int d, const double* ls,
+                    int ls_len, double* out, hipStream_t st);
+void launch_process_cov(const double* in, long long n, double scale, double noise, double* out,
+                        hipStream_t st);
+
+// unit B (full ITE covariance) helpers
+struct DtArgs {
+    const double* X; const double* T; SampleParams p; long long s0;
+    int n, nX, nU, nt; double doT; double pred_noise;
+    TRef W;    // nt x nt rectangular: receives D (rows = i, cols = j), D_ij = B_ij (r_j - e_ij)
+    TRef Cm;   // lower packed nt: receives Delta + pred_noise*I (identity on the padding)
+};
+void launch_dt_build(const DtArgs& a, int nbatch, hipStream_t st);
+
+struct GatherCovArgs {
+    TRef Cm; int n, nt; long long s0, S; double* out; // out: S x n x n, sample fastest
+};
+void launch_gather_cov(const GatherCovArgs& a, int nbatch, hipStream_t st);
+
+struct DrawArgs {
+    TRef Lc; int n, nt; long long s0, S; int l, L, spp;
+    const double* mean;   // meanITE n x S x L
+    const double* z;      // n x spp x S x L or null
+    unsigned long long seed;
+    double* out;          // L x n x (S*spp)
+};
+void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st);

@@ -1,0 +1,337 @@
+// Gram-matrix build and the O(N^2)/O(N) pieces around the factorisation.
+//
+//   gram_kernel        A = yScale*exp(Lu+Lx) .* exp(Lt) + yNoise*I   (src/kernel.jl:13-32, 53-59;
+//                      src/likelihood.jl:24-32; src/model_likelihood.jl:83-120), lower tiles only,
+//                      fused with the per-tile partial column sums of B = yScale*exp(Lu+Lx) and
+//                      K = B.*E that the SATE path needs.
+//   rhs_prepare/tiles  column sums -> augmented right-hand sides [Y, c(1..L)] and sum(Delta).
+//   epilogue           Schur complement of the augmented block -> MeanSATE, VarSATE, logdet, quad.
+//   rbf_log / process_cov  the two src/kernel.jl entry points as stand-alone dense kernels.
+#include "gpslc_internal.h"
+
+#define MAXF 32   // max nU + nX handled by the fused Gram kernel
+
+// block-wide sum with a fixed reduction tree (deterministic); result valid in every thread
+__device__ __forceinline__ double block_sum_256(double v, double* red /* >= 4 doubles */) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Gram build: one workgroup per lower tile (ti >= tj) per posterior sample.
+// Thread (tx = tid>>4, ty = tid&15) owns rows ty + 16p and columns 8 tx + q, p, q = 0..7.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int F = g.nU + g.nX;
+    double* fr = sm;                     // [F][128] row-block features
+    double* fc = fr + MAXF * GP_TS;      // [F][128] column-block features
+    double* tr = fc + MAXF * GP_TS;      // [128] T of row block
+    double* tc = tr + GP_TS;             // [128]
+    double* wf = tc + GP_TS;             // [MAXF] 1 / LS^2
+    double* red = wf + MAXF;             // [4][128][2] cross-wave row-sum staging
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const long long s = g.s0 + b;
+    int ti, tj;
+    {
+        const int t = blockIdx.x;
+        int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((long long)(r + 1) * (r + 2) / 2 <= t) ++r;
+        while ((long long)r * (r + 1) / 2 > t) --r;
+        ti = r; tj = t - r * (r + 1) / 2;
+    }
+    const int n = g.n;
+    const int gi0 = ti * GP_TS, gj0 = tj * GP_TS;
+
+    // stage features (zeros on the padding)
+    for (int idx = tid; idx < F * GP_TS; idx += 256) {
+        const int f = idx >> 7, r = idx & 127;
+        const double* src; long long ld;
+        if (f < g.nU) { src = g.p.U + (s * g.nU + f) * (long long)n; ld = 0; }
+        else { src = g.X + (long long)(f - g.nU) * n; ld = 0; }
+        (void)ld;
+        fr[f * GP_TS + r] = (gi0 + r < n) ? src[gi0 + r] : 0.0;
+        fc[f * GP_TS + r] = (gj0 + r < n) ? src[gj0 + r] : 0.0;
+    }
+    if (tid < GP_TS) {
+        tr[tid] = (gi0 + tid < n) ? g.T[gi0 + tid] : 0.0;
+        tc[tid] = (gj0 + tid < n) ? g.T[gj0 + tid] : 0.0;
+    }
+    if (tid < F) {
+        const double l = (tid < g.nU) ? g.p.uyLS[s * g.nU + tid] : g.p.xyLS[s * g.nX + (tid - g.nU)];
+        wf[tid] = 1.0 / (l * l);
+    }
+    __syncthreads();
+
+    const double ys = g.p.yScale[s];
+    const double yn = g.p.yNoise[s];
+    const double tl = g.p.tyLS[s];
+    const double wt = 1.0 / (tl * tl);
+    const int ty = tid & 15, tx = tid >> 4;
+
+    double tra[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) tra[p] = tr[ty + 16 * p];
+
+    double* tile = tref_tile(g.M, b, ti, tj);
+    const int Np = g.nt * GP_TS;
+    double* partB = g.part + ((long long)b * 2 + 0) * g.nt * Np;
+    double* partK = g.part + ((long long)b * 2 + 1) * g.nt * Np;
+    double rsB[8], rsK[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { rsB[p] = 0.0; rsK[p] = 0.0; }
+
+    // runtime loop over this thread's 8 columns keeps the (inlined) exp code small enough for the
+    // instruction cache; the row features are re-read from LDS per column (cheap next to 16 exps)
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+        const int cq = 8 * tx + q;
+        const int gj = gj0 + cq;
+        double lux[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) lux[p] = 0.0;
+        for (int f = 0; f < F; ++f) {
+            const double w = wf[f];
+            const double c = fc[f * GP_TS + cq];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const double d = fr[f * GP_TS + ty + 16 * p] - c;
+                lux[p] += (d * d) * w;
+            }
+        }
+        const double tcq = tc[cq];
+        double csB = 0.0, csK = 0.0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int rp = ty + 16 * p;
+            const int gi = gi0 + rp;
+            const double dt = tra[p] - tcq;
+            double Bv = ys * exp(-lux[p]);
+            double Ev = exp(-((dt * dt) * wt));
+            double Kv = Bv * Ev;
+            double Av = Kv;
+            const bool inside = (gi < n) && (gj < n);
+            if (!inside) { Bv = 0.0; Kv = 0.0; Av = (gi == gj) ? 1.0 : 0.0; }
+            else if (gi == gj) Av = Kv + yn;
+            tile[cq * GP_TS + rp] = Av;
+            rsB[p] += Bv; rsK[p] += Kv;
+            csB += Bv; csK += Kv;
+        }
+        if (g.with_sums) {
+            // column sums: reduce over the 16 ty lanes (lane bits 0..3)
+#pragma unroll
+            for (int o = 1; o <= 8; o <<= 1) { csB += __shfl_xor(csB, o, 64); csK += __shfl_xor(csK, o, 64); }
+            if (ty == 0) {
+                partB[(long long)ti * Np + gj] = csB;
+                partK[(long long)ti * Np + gj] = csK;
+            }
+        }
+    }
+    if (!g.with_sums) return;
+    if (ti == tj) return;   // diagonal tile: the full square was computed, column sums are complete
+
+    // row sums: reduce over tx = (lane>>4) + 4*wave : lane bits 4..5, then the 4 waves through LDS
+    const int wave = tid >> 6, lane = tid & 63;
+    __syncthreads();   // all feature reads done before `red` (aliasing nothing, but keep phases clean)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        double vb = rsB[p], vk = rsK[p];
+        vb += __shfl_xor(vb, 16, 64); vk += __shfl_xor(vk, 16, 64);
+        vb += __shfl_xor(vb, 32, 64); vk += __shfl_xor(vk, 32, 64);
+        if (lane < 16) {
+            red[(wave * GP_TS + ty + 16 * p) * 2 + 0] = vb;
+            red[(wave * GP_TS + ty + 16 * p) * 2 + 1] = vk;
+        }
+    }
+    __syncthreads();
+    if (tid < GP_TS) {
+        const double vb = (red[(0 * GP_TS + tid) * 2] + red[(1 * GP_TS + tid) * 2]) +
+                          (red[(2 * GP_TS + tid) * 2] + red[(3 * GP_TS + tid) * 2]);
+        const double vk = (red[(0 * GP_TS + tid) * 2 + 1] + red[(1 * GP_TS + tid) * 2 + 1]) +
+                          (red[(2 * GP_TS + tid) * 2 + 1] + red[(3 * GP_TS + tid) * 2 + 1]);
+        partB[(long long)tj * Np + gi0 + tid] = vb;
+        partK[(long long)tj * Np + gi0 + tid] = vk;
+    }
+}
+
+#define GRAM_LDS_BYTES ((2 * MAXF * GP_TS + 2 * GP_TS + MAXF + 4 * GP_TS * 2) * 8)
+
+void launch_gram(const GramArgs& g, int nbatch, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GRAM_LDS_BYTES);
+        attr_set = true;
+    }
+    const int nlow = g.nt * (g.nt + 1) / 2;
+    hipLaunchKernelGGL(gram_kernel, dim3(nlow, nbatch), dim3(256), GRAM_LDS_BYTES, st, g);
+}
+
+// ---------------------------------------------------------------------------------------
+// rhs_prepare: per sample, reduce the per-tile partial sums in a fixed order, form the totals and
+// sum(Delta_l) = sum K - 2 r.bsum + sum B for every level.  One workgroup per sample.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rhs_prepare_kernel(RhsArgs a) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const long long s = a.s0 + b;
+    const int Np = a.nt * GP_TS;
+    const double* partB = a.part + ((long long)b * 2 + 0) * a.nt * Np;
+    const double* partK = a.part + ((long long)b * 2 + 1) * a.nt * Np;
+    double* bs = a.bsum + (long long)b * Np;
+    double* ks = a.ksum + (long long)b * Np;
+    double tb = 0.0, tk = 0.0;
+    for (int j = tid; j < Np; j += 256) {
+        double vb = 0.0, vk = 0.0;
+        for (int slot = 0; slot < a.nt; ++slot) {
+            vb += partB[(long long)slot * Np + j];
+            vk += partK[(long long)slot * Np + j];
+        }
+        bs[j] = vb; ks[j] = vk;
+        tb += vb; tk += vk;
+    }
+    const double btot = block_sum_256(tb, red);
+    const double ktot = block_sum_256(tk, red);
+    const double tl = a.tyLS[s];
+    const double wt = 1.0 / (tl * tl);
+    for (int l = 0; l < a.L; ++l) {
+        const double dot = a.doT[l];
+        double acc = 0.0;
+        for (int j = tid; j < Np; j += 256) {
+            // same thread -> j assignment and the same tree as btot, so r == 1 reproduces btot bit for bit
+            const double dt = (j < a.n ? a.T[j] : 0.0) - dot;
+            const double r = exp(-((dt * dt) * wt));
+            acc += r * bs[j];
+        }
+        const double rb = block_sum_256(acc, red);
+        if (tid == 0) a.sumdelta[(long long)b * a.L + l] = (ktot - 2.0 * rb) + btot;
+    }
+}
+
+// rhs_tiles: write the augmented row tiles: row q of the augmented block is right-hand side q
+// (q = 0: Y, q = 1 + l: c_l = r_l .* bsum - ksum), zero elsewhere; zero the aug x aug tiles.
+// grid (nt + naug, naug, batch): tile (nt + a, j) with j = blockIdx.x, a = blockIdx.y (j <= nt + a).
+__global__ __launch_bounds__(256) void rhs_tiles_kernel(RhsArgs a) {
+    const int tid = threadIdx.x;
+    const int j = blockIdx.x, au = blockIdx.y, b = blockIdx.z;
+    if (j > a.nt + au) return;
+    const long long s = a.s0 + b;
+    double* tile = tref_tile(a.M, b, a.nt + au, j);
+    if (j >= a.nt) {
+        for (int idx = tid; idx < GP_TSQ; idx += 256) tile[idx] = 0.0;
+        return;
+    }
+    const int Np = a.nt * GP_TS;
+    const double* bs = a.bsum + (long long)b * Np;
+    const double* ks = a.ksum + (long long)b * Np;
+    const double tl = a.tyLS[s];
+    const double wt = 1.0 / (tl * tl);
+    // element (row q, col c) at c*128 + q; thread -> consecutive q for coalescing
+    for (int idx = tid; idx < GP_TSQ; idx += 256) {
+        const int c = idx >> 7, q = idx & 127;
+        const int gq = au * GP_TS + q;        // right-hand side index
+        const int gj = j * GP_TS + c;         // instance index
+        double v = 0.0;
+        if (gj < a.n) {
+            if (gq == 0) v = a.Y[gj];
+            else if (gq <= a.L) {
+                const double dt = a.T[gj] - a.doT[gq - 1];
+                const double r = exp(-((dt * dt) * wt));
+                v = r * bs[gj] - ks[gj];
+            }
+        }
+        tile[idx] = v;
+    }
+}
+
+void launch_rhs(const RhsArgs& r, int nbatch, hipStream_t st) {
+    if (r.with_sums) hipLaunchKernelGGL(rhs_prepare_kernel, dim3(nbatch), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(rhs_tiles_kernel, dim3(r.nt + r.naug, r.naug, nbatch), dim3(256), 0, st, r);
+}
+
+// ---------------------------------------------------------------------------------------
+// epilogue: after the augmented factorisation tile (nt+a, nt+a') holds G = -R R^T with
+// R = [z, w_1 .. w_L] (z = L^-1 Y, w_l = L^-1 c_l).  One workgroup per sample.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void epilogue_kernel(EpiArgs e) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const long long s = e.s0 + b;
+    // log-determinant: 2 * sum log L_ii over the real rows
+    double acc = 0.0;
+    for (int i = tid; i < e.n; i += 256) {
+        const int k = i >> 7, c = i & 127;
+        const double* dt = tref_tile(e.M, b, k, k);
+        acc += log(dt[c * GP_TS + c]);
+    }
+    const double ld = 2.0 * block_sum_256(acc, red);
+    const double* g00 = tref_tile(e.M, b, e.nt, e.nt);
+    if (tid == 0) {
+        if (e.logdet) e.logdet[s] = ld;
+        if (e.quad) e.quad[s] = -g00[0];
+    }
+    if (e.meanSATE == nullptr && e.varSATE == nullptr) return;
+    const double nn = (double)e.n;
+    for (int l = tid; l < e.L; l += 256) {
+        const int q = 1 + l, au = q >> 7, qq = q & 127;
+        const double wz = -tref_tile(e.M, b, e.nt + au, e.nt)[0 * GP_TS + qq];
+        const double ww = -tref_tile(e.M, b, e.nt + au, e.nt + au)[qq * GP_TS + qq];
+        const double sd = e.sumdelta[(long long)b * e.L + l];
+        if (e.meanSATE) e.meanSATE[s + e.S * l] = wz / nn;
+        if (e.varSATE) e.varSATE[s + e.S * l] = ((sd - ww) + nn * e.pred_noise) / (nn * nn);
+    }
+}
+
+void launch_epilogue(const EpiArgs& e, int nbatch, hipStream_t st) {
+    hipLaunchKernelGGL(epilogue_kernel, dim3(nbatch), dim3(256), 0, st, e);
+}
+
+// ---------------------------------------------------------------------------------------
+// src/kernel.jl:24-32 rbfKernelLog and :53-59 processCov as plain dense kernels (column-major
+// n x n, both triangles) for the Julia-visible entry points.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rbf_log_kernel(const double* X1, const double* X2, long long n,
+                                                      int d, const double* ls, int ls_len, double* out) {
+    // 16 x 16 thread tile, i fastest (column-major output: out[i + n*ip])
+    const long long i = (long long)blockIdx.x * 16 + (threadIdx.x & 15);
+    const long long ip = (long long)blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (i >= n || ip >= n) return;
+    double acc = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const double l = ls[ls_len == 1 ? 0 : k];
+        const double df = X1[i + n * k] - X2[ip + n * k];
+        acc += (df * df) / (l * l);
+    }
+    out[i + n * ip] = -acc;
+}
+
+void launch_rbf_log(const double* X1, const double* X2, long long n, int d, const double* ls,
+                    int ls_len, double* out, hipStream_t st) {
+    dim3 grid((unsigned)((n + 15) / 16), (unsigned)((n + 15) / 16));
+    hipLaunchKernelGGL(rbf_log_kernel, grid, dim3(256), 0, st, X1, X2, n, d, ls, ls_len, out);
+}
+
+__global__ __launch_bounds__(256) void process_cov_kernel(const double* in, long long n, double scale,
+                                                          double noise, double* out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const long long i = idx % n, j = idx / n;
+    double v = exp(in[idx]) * scale;
+    if (i == j) v += noise;
+    out[idx] = v;
+}
+
+void launch_process_cov(const double* in, long long n, double scale, double noise, double* out,
+                        hipStream_t st) {
+    const long long tot = n * n;
+    hipLaunchKernelGGL(process_cov_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, in, n,
+                       scale, noise, out);
+}

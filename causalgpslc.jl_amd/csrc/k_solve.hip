@@ -1,0 +1,383 @@
+// O(N^2) kernels around the factor: back-substitution for alpha = A^-1 Y, the MeanITE pass,
+// construction of D / Delta for the full ITE covariance, CovITE gather and the predictive draws.
+#include "gpslc_internal.h"
+
+#define MAXF 32
+
+// ---------------------------------------------------------------------------------------
+// Back-substitution L^T alpha = z as nt dependent launches (right-looking):
+// launch i: every workgroup (k <= i, b) recomputes alpha_i = inv(L_ii)^T z_i (bit-identical in all
+// of them); workgroup k == i publishes alpha_i, workgroups k < i update z_k -= L(i,k)^T alpha_i.
+// z_i is only read in launch i, so there is no intra-launch hazard.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void backsolve_step_kernel(BackArgs a, int i, double* alpha) {
+    __shared__ double zi[GP_TS];
+    __shared__ double ai[GP_TS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = blockIdx.x;
+    const long long b = blockIdx.y;
+    const int Np = a.nt * GP_TS;
+    double* z = a.zwork + b * Np;
+    if (tid < GP_TS) zi[tid] = z[i * GP_TS + tid];
+    __syncthreads();
+    const double* invt = a.inv + b * a.inv_bstride + (long long)i * GP_TSQ;
+    // (inv^T z)_c = sum_r inv[r][c] z[r]; wave w handles columns w*32 .. w*32+31, lanes stride r
+    for (int cc = 0; cc < 32; ++cc) {
+        const int c = wave * 32 + cc;
+        double v = invt[c * GP_TS + lane] * zi[lane] + invt[c * GP_TS + lane + 64] * zi[lane + 64];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) ai[c] = v;
+    }
+    __syncthreads();
+    if (k == i) {
+        if (tid < GP_TS) alpha[b * Np + i * GP_TS + tid] = ai[tid];
+        return;
+    }
+    const double* t = tref_tile(a.M, b, i, k);
+    for (int cc = 0; cc < 32; ++cc) {
+        const int c = wave * 32 + cc;
+        double v = t[c * GP_TS + lane] * ai[lane] + t[c * GP_TS + lane + 64] * ai[lane + 64];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) z[k * GP_TS + c] -= v;
+    }
+}
+
+// copy z = row 0 of the augmented tile row (nt, j) into zwork
+__global__ __launch_bounds__(128) void extract_z_kernel(BackArgs a) {
+    const int j = blockIdx.x;
+    const long long b = blockIdx.y;
+    const double* t = tref_tile(a.M, b, a.nt, j);
+    a.zwork[b * a.nt * GP_TS + j * GP_TS + threadIdx.x] = t[threadIdx.x * GP_TS + 0];
+}
+
+void launch_backsolve(const BackArgs& a, int nbatch, hipStream_t st) {
+    // alpha is stored right behind zwork (caller allocates 2 * nbatch * Np doubles)
+    double* alpha = a.zwork + (long long)nbatch * a.nt * GP_TS;
+    hipLaunchKernelGGL(extract_z_kernel, dim3(a.nt, nbatch), dim3(128), 0, st, a);
+    for (int i = a.nt - 1; i >= 0; --i)
+        hipLaunchKernelGGL(backsolve_step_kernel, dim3(i + 1, nbatch), dim3(256), 0, st, a, i, alpha);
+}
+
+// ---------------------------------------------------------------------------------------
+// MeanITE_i(l) = sum_j B_ij (r_j(l) - e_ij) alpha_j   (src/estimation.jl:46 with
+// D = Ks' - K formed element-wise so that doT == T gives exact zeros, test/estimation.jl:6-66).
+// One workgroup per (row block, sample); levels are processed LC at a time.
+// ---------------------------------------------------------------------------------------
+#define LC 16
+__global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int F = a.nU + a.nX;
+    double* fr = sm;                       // [MAXF][128]
+    double* fc = fr + MAXF * GP_TS;        // [MAXF][128]
+    double* tcs = fc + MAXF * GP_TS;       // [128]
+    double* al = tcs + GP_TS;              // [128]
+    double* rl = al + GP_TS;               // [LC][128]
+    double* wf = rl + LC * GP_TS;          // [MAXF]
+    double* red = wf + MAXF;               // [128][LC]
+    const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;
+    const int ib = blockIdx.x;
+    const long long b = blockIdx.y, s = a.s0 + b;
+    const int n = a.n, Np = a.nt * GP_TS;
+    const int gi = ib * GP_TS + r;
+
+    auto feat_src = [&](int f) -> const double* {
+        return (f < a.nU) ? a.p.U + (s * a.nU + f) * (long long)n : a.X + (long long)(f - a.nU) * n;
+    };
+    for (int idx = tid; idx < F * GP_TS; idx += 256) {
+        const int f = idx >> 7, rr = idx & 127;
+        const int g = ib * GP_TS + rr;
+        fr[idx] = (g < n) ? feat_src(f)[g] : 0.0;
+    }
+    if (tid < F) {
+        const double l = (tid < a.nU) ? a.p.uyLS[s * a.nU + tid] : a.p.xyLS[s * a.nX + (tid - a.nU)];
+        wf[tid] = 1.0 / (l * l);
+    }
+    const double ys = a.p.yScale[s];
+    const double tl = a.p.tyLS[s];
+    const double wt = 1.0 / (tl * tl);
+    const double tri = (gi < n) ? a.T[gi] : 0.0;
+    const double* alpha = a.alpha + b * Np;
+
+    for (int l0 = 0; l0 < a.L; l0 += LC) {
+        const int nl = min(LC, a.L - l0);
+        double acc[LC];
+#pragma unroll
+        for (int ll = 0; ll < LC; ++ll) acc[ll] = 0.0;
+        for (int jt = 0; jt < a.nt; ++jt) {
+            __syncthreads();
+            for (int idx = tid; idx < F * GP_TS; idx += 256) {
+                const int f = idx >> 7, cc = idx & 127;
+                const int g = jt * GP_TS + cc;
+                fc[idx] = (g < n) ? feat_src(f)[g] : 0.0;
+            }
+            if (tid < GP_TS) {
+                const int g = jt * GP_TS + tid;
+                tcs[tid] = (g < n) ? a.T[g] : 0.0;
+                al[tid] = (g < n) ? alpha[g] : 0.0;
+            }
+            for (int idx = tid; idx < LC * GP_TS; idx += 256) {
+                const int ll = idx >> 7, cc = idx & 127;
+                const int g = jt * GP_TS + cc;
+                double v = 0.0;
+                if (ll < nl && g < n) {
+                    const double dt = a.T[g] - a.doT[l0 + ll];
+                    v = exp(-((dt * dt) * wt));
+                }
+                rl[idx] = v;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int cq = 0; cq < 64; ++cq) {
+                const int c = h * 64 + cq;
+                double lux = 0.0;
+                for (int f = 0; f < F; ++f) {
+                    const double d = fr[f * GP_TS + r] - fc[f * GP_TS + c];
+                    lux += (d * d) * wf[f];
+                }
+                const double dt = tri - tcs[c];
+                const double Bv = ys * exp(-lux);
+                const double Ev = exp(-((dt * dt) * wt));
+                const double ba = Bv * al[c];
+#pragma unroll
+                for (int ll = 0; ll < LC; ++ll) acc[ll] += ba * (rl[ll * GP_TS + c] - Ev);
+            }
+        }
+        __syncthreads();
+        if (h == 1) {
+#pragma unroll
+            for (int ll = 0; ll < LC; ++ll) red[r * LC + ll] = acc[ll];
+        }
+        __syncthreads();
+        if (h == 0 && gi < n) {
+#pragma unroll
+            for (int ll = 0; ll < LC; ++ll)
+                if (ll < nl)
+                    a.meanITE[(long long)gi * a.si + s * a.ss + (long long)(l0 + ll) * a.sl] =
+                        acc[ll] + red[r * LC + ll];
+        }
+    }
+}
+#define ITEMEAN_LDS_BYTES ((2 * MAXF * GP_TS + 2 * GP_TS + LC * GP_TS + MAXF + GP_TS * LC) * 8)
+
+void launch_ite_mean(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ite_mean_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, ITEMEAN_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ite_mean_kernel, dim3(a.nt, nbatch), dim3(256), ITEMEAN_LDS_BYTES, st, a);
+}
+
+// ---------------------------------------------------------------------------------------
+// dt_build: tiles of D (D_ij = B_ij (r_j - e_ij), src/estimation.jl:46 "CovWWs' - CovWW") into the
+// rectangular matrix W and Delta + pred_noise*I (Delta_ij = B_ij (e_ij - r_i - r_j + 1) =
+// CovWW - CovWWs - CovWWs' + CovWsWs, src/likelihood.jl:46-49 / estimation.jl:47, :82) into Cm.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dt_build_kernel(DtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int F = a.nU + a.nX;
+    double* fr = sm;
+    double* fc = fr + MAXF * GP_TS;
+    double* tr = fc + MAXF * GP_TS;
+    double* tc = tr + GP_TS;
+    double* rr_ = tc + GP_TS;   // r_i of the row block
+    double* rc_ = rr_ + GP_TS;  // r_j of the column block
+    double* wf = rc_ + GP_TS;
+    const int tid = threadIdx.x;
+    const int ti = blockIdx.x / a.nt, tj = blockIdx.x % a.nt;
+    const long long b = blockIdx.y, s = a.s0 + b;
+    const int n = a.n;
+    const int gi0 = ti * GP_TS, gj0 = tj * GP_TS;
+    const double tl = a.p.tyLS[s];
+    const double wt = 1.0 / (tl * tl);
+    for (int idx = tid; idx < F * GP_TS; idx += 256) {
+        const int f = idx >> 7, r = idx & 127;
+        const double* src = (f < a.nU) ? a.p.U + (s * a.nU + f) * (long long)n
+                                       : a.X + (long long)(f - a.nU) * n;
+        fr[idx] = (gi0 + r < n) ? src[gi0 + r] : 0.0;
+        fc[idx] = (gj0 + r < n) ? src[gj0 + r] : 0.0;
+    }
+    if (tid < GP_TS) {
+        const double t1 = (gi0 + tid < n) ? a.T[gi0 + tid] : 0.0;
+        const double t2 = (gj0 + tid < n) ? a.T[gj0 + tid] : 0.0;
+        tr[tid] = t1; tc[tid] = t2;
+        const double d1 = t1 - a.doT, d2 = t2 - a.doT;
+        rr_[tid] = exp(-((d1 * d1) * wt));
+        rc_[tid] = exp(-((d2 * d2) * wt));
+    }
+    if (tid < F) {
+        const double l = (tid < a.nU) ? a.p.uyLS[s * a.nU + tid] : a.p.xyLS[s * a.nX + (tid - a.nU)];
+        wf[tid] = 1.0 / (l * l);
+    }
+    __syncthreads();
+    const double ys = a.p.yScale[s];
+    const int ty = tid & 15, tx = tid >> 4;
+    double* wt_tile = tref_tile(a.W, b, ti, tj);
+    double* c_tile = (ti >= tj) ? tref_tile(a.Cm, b, ti, tj) : nullptr;
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+        const int cq = 8 * tx + q;
+        const int gj = gj0 + cq;
+        double lux[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) lux[p] = 0.0;
+        for (int f = 0; f < F; ++f) {
+            const double w = wf[f];
+            const double c = fc[f * GP_TS + cq];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const double d = fr[f * GP_TS + ty + 16 * p] - c;
+                lux[p] += (d * d) * w;
+            }
+        }
+        const double tcq = tc[cq], rj = rc_[cq];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int rp = ty + 16 * p;
+            const int gi = gi0 + rp;
+            const double dt = tr[rp] - tcq;
+            const double Bv = ys * exp(-lux[p]);
+            const double Ev = exp(-((dt * dt) * wt));
+            const double ri = rr_[rp];
+            double Dv = Bv * (rj - Ev);
+            double Cv = Bv * (((Ev - ri) - rj) + 1.0);
+            const bool inside = (gi < n) && (gj < n);
+            if (!inside) { Dv = 0.0; Cv = (gi == gj) ? 1.0 : 0.0; }
+            else if (gi == gj) Cv += a.pred_noise;
+            wt_tile[cq * GP_TS + rp] = Dv;
+            if (c_tile) c_tile[cq * GP_TS + rp] = Cv;
+        }
+    }
+}
+#define DT_LDS_BYTES ((2 * MAXF * GP_TS + 4 * GP_TS + MAXF) * 8)
+
+void launch_dt_build(const DtArgs& a, int nbatch, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)dt_build_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(dt_build_kernel, dim3(a.nt * a.nt, nbatch), dim3(256), DT_LDS_BYTES, st, a);
+}
+
+// CovITEs[s + S*(i + n*j)] (src/estimation.jl:75, :82 layout: sample index fastest), both triangles
+__global__ __launch_bounds__(256) void gather_cov_kernel(GatherCovArgs a) {
+    int ti, tj;
+    {
+        const int t = blockIdx.x;
+        int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((long long)(r + 1) * (r + 2) / 2 <= t) ++r;
+        while ((long long)r * (r + 1) / 2 > t) --r;
+        ti = r; tj = t - r * (r + 1) / 2;
+    }
+    const long long b = blockIdx.y, s = a.s0 + b;
+    const double* t = tref_tile(a.Cm, b, ti, tj);
+    for (int idx = threadIdx.x; idx < GP_TSQ; idx += 256) {
+        const int c = idx >> 7, r = idx & 127;
+        const long long gi = (long long)ti * GP_TS + r, gj = (long long)tj * GP_TS + c;
+        if (gi >= a.n || gj >= a.n || gi < gj) continue;
+        const double v = t[idx];
+        a.out[s + a.S * (gi + a.n * gj)] = v;
+        a.out[s + a.S * (gj + a.n * gi)] = v;
+    }
+}
+void launch_gather_cov(const GatherCovArgs& a, int nbatch, hipStream_t st) {
+    hipLaunchKernelGGL(gather_cov_kernel, dim3(a.nt * (a.nt + 1) / 2, nbatch), dim3(256), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------
+// Predictive draws: ite[l, i, s*spp + d] = MeanITE_i + (L_c z)_i  (src/estimation.jl:95-109 with the
+// factor computed once per (sample, level) instead of once per draw).
+// Philox4x32-10 + Box-Muller, restated in oracle/gpslc_oracle.py:philox_normals.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                              unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int rd = 0; rd < 10; ++rd) {
+        const unsigned long long p0 = 0xD2511F53ull * c0;
+        const unsigned long long p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double philox_normal(unsigned long long seed, unsigned long long stream,
+                                                unsigned long long e) {
+    unsigned w[4];
+    const unsigned long long pair = e >> 1;
+    philox4x32_10((unsigned)pair, (unsigned)(pair >> 32), (unsigned)stream, (unsigned)(stream >> 32),
+                  (unsigned)seed, (unsigned)(seed >> 32), w);
+    const unsigned long long A = ((unsigned long long)w[0] << 21) ^ ((unsigned long long)w[1] >> 11);
+    const unsigned long long Bq = ((unsigned long long)w[2] << 21) ^ ((unsigned long long)w[3] >> 11);
+    const double u1 = ((double)A + 0.5) * (1.0 / 9007199254740992.0);
+    const double u2 = ((double)Bq + 0.5) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    const double ang = 6.283185307179586476925286766559 * u2;
+    return (e & 1ull) ? rad * sin(ang) : rad * cos(ang);
+}
+
+#define DC 8
+__global__ __launch_bounds__(256) void draws_kernel(DrawArgs a) {
+    __shared__ double zs[DC][GP_TS];
+    __shared__ double red[GP_TS][DC];
+    const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;
+    const int ib = blockIdx.x;
+    const long long b = blockIdx.y, s = a.s0 + b;
+    const long long n = a.n;
+    const long long gi = (long long)ib * GP_TS + r;
+    const unsigned long long stream = (unsigned long long)(s + a.S * a.l);
+    for (int d0 = 0; d0 < a.spp; d0 += DC) {
+        const int nd = min(DC, a.spp - d0);
+        double acc[DC];
+#pragma unroll
+        for (int dd = 0; dd < DC; ++dd) acc[dd] = 0.0;
+        for (int jt = 0; jt <= ib; ++jt) {
+            __syncthreads();
+            for (int idx = tid; idx < DC * GP_TS; idx += 256) {
+                const int dd = idx >> 7, cc = idx & 127;
+                const long long g = (long long)jt * GP_TS + cc;
+                double v = 0.0;
+                if (dd < nd && g < n) {
+                    const long long d = d0 + dd;
+                    if (a.z) v = a.z[g + n * (d + a.spp * (s + a.S * (long long)a.l))];
+                    else v = philox_normal(a.seed, stream, (unsigned long long)(g + n * d));
+                }
+                zs[dd][cc] = v;
+            }
+            __syncthreads();
+            const double* t = tref_tile(a.Lc, b, ib, jt);
+#pragma unroll 4
+            for (int cq = 0; cq < 64; ++cq) {
+                const int c = h * 64 + cq;
+                const double v = t[c * GP_TS + r];
+#pragma unroll
+                for (int dd = 0; dd < DC; ++dd) acc[dd] += v * zs[dd][c];
+            }
+        }
+        __syncthreads();
+        if (h == 1) {
+#pragma unroll
+            for (int dd = 0; dd < DC; ++dd) red[r][dd] = acc[dd];
+        }
+        __syncthreads();
+        if (h == 0 && gi < n) {
+            const double mu = a.mean[gi + n * (s + a.S * (long long)a.l)];
+#pragma unroll
+            for (int dd = 0; dd < DC; ++dd)
+                if (dd < nd)
+                    a.out[a.l + (long long)a.L * (gi + n * (s * a.spp + d0 + dd))] =
+                        mu + (acc[dd] + red[r][dd]);
+        }
+    }
+}
+void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st) {
+    hipLaunchKernelGGL(draws_kernel, dim3(a.nt, nbatch), dim3(256), 0, st, a);
+}

@@ -1,0 +1,151 @@
+/*
+ * gpslc_hip.h — C ABI of libgpslc_hip.so, the MI355X (gfx950) implementation of the
+ * CausalGPSLC.jl GP-kernel + posterior-prediction hot path.
+ *
+ * Every entry point replaces the body of one Julia function of the reference (cited per
+ * function, paths relative to the reference repository).  The Julia side keeps its
+ * signatures and `ccall`s these (INTEGRATION.md shows the shim); in this repository a
+ * Python ctypes harness (causalgpslc.jl_amd/_lib.py) binds exactly the same symbols.
+ *
+ * Conventions
+ *   - all matrices are COLUMN-MAJOR (Julia layout), all reals are IEEE double;
+ *   - Bool treatments are pre-converted by the caller to 0.0 / 1.0 (Julia promotes Bool on
+ *     subtraction, src/kernel.jl:17);
+ *   - return value: 0 = ok; < 0 = error (GPSLC_ERR_*; -1..-99 = "argument #k is invalid");
+ *     > 0 = 1-based index of the pivot at which a Cholesky factorisation broke down
+ *     (the Julia shim rethrows it as PosDefException(info), mirroring PDMats);
+ *   - no C++ exception, abort or longjmp crosses this boundary;
+ *   - the caller owns every host/device buffer it passes; the library keeps no pointer to
+ *     caller memory after a call returns; device workspace belongs to the ctx;
+ *   - calls on one ctx must be serialised by the caller; use one ctx per GPU / per thread.
+ *   - "_dev" variants take DEVICE pointers (hipMalloc'ed / torch / AMDGPU.jl memory on the
+ *     ctx's device) for every array argument; the plain variants take HOST pointers.
+ */
+#ifndef GPSLC_HIP_H
+#define GPSLC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpslc_ctx gpslc_ctx;
+
+#define GPSLC_OK                 0
+#define GPSLC_ERR_HIP        (-1000)  /* a HIP runtime call failed; see gpslc_last_error  */
+#define GPSLC_ERR_NOMEM      (-1001)  /* device workspace could not be allocated          */
+#define GPSLC_ERR_NODATA     (-1002)  /* gpslc_set_data has not been called               */
+#define GPSLC_ERR_NODEVICE   (-1003)  /* no usable gfx950 device                          */
+#define GPSLC_ERR_INTERNAL   (-1004)
+
+/* flags for gpslc_create */
+#define GPSLC_FLAG_DEFAULT            0u
+#define GPSLC_FLAG_PROFILE            1u   /* record HIP events around the dominant kernels */
+
+/* ---- context ------------------------------------------------------------------------- */
+
+/* One context per (GPU, data set).  n = instances, nX = covariate columns (0 = model without
+ * X), nU = latent confounder columns (0 = model without U).  Plays the role of the data part
+ * of GPSLCObject (src/types.jl:249-258). */
+int gpslc_create(gpslc_ctx** out, int device, int64_t n, int32_t nX, int32_t nU, uint32_t flags);
+int gpslc_destroy(gpslc_ctx* ctx);
+
+/* g.X (n x nX, may be NULL when nX == 0), g.T (n), g.Y (n): src/types.jl:249-258. */
+int gpslc_set_data(gpslc_ctx* ctx, const double* X, const double* T, const double* Y);
+int gpslc_set_data_dev(gpslc_ctx* ctx, const double* X, const double* T, const double* Y);
+
+/* Tuning knobs (0 = keep default): max posterior samples factorised concurrently, tile-panel
+ * width of the blocked Cholesky, number of HIP streams chunks are spread over. */
+int gpslc_set_tuning(gpslc_ctx* ctx, int32_t max_batch, int32_t panel_tiles, int32_t n_streams);
+
+const char* gpslc_last_error(const gpslc_ctx* ctx);
+
+/* ---- src/kernel.jl ------------------------------------------------------------------- */
+
+/* rbfKernelLog(X1, X2, LS) (src/kernel.jl:24-32; vectors are d = 1):
+ * out[i + n*ip] = -sum_k (X1[i,k] - X2[ip,k])^2 / LS[k]^2, ls_len = 1 (scalar LS) or d. */
+int gpslc_rbf_log(gpslc_ctx* ctx, const double* X1, const double* X2, int64_t n, int32_t d,
+                  const double* ls, int32_t ls_len, double* out);
+
+/* processCov(logCov, scale[, noise]) (src/kernel.jl:53-55, 57-59): out = exp.(logcov)*scale
+ * + noise*I.  The two-argument method is noise = 0.0. */
+int gpslc_process_cov(gpslc_ctx* ctx, const double* logcov, int64_t n, double scale, double noise,
+                      double* out);
+
+/* ---- src/model_likelihood.jl :Y node -------------------------------------------------- */
+
+/* logpdf(MvNormal(0, Symmetric(Ycov)), Y) with Ycov = processCov(uyCovLog .+ xyCovLog .+
+ * tyCovLog, yScale, yNoise): generateYfromUXT / UT / XT / T (src/model_likelihood.jl:83-91,
+ * 94-101, 104-111, 114-120).  U: n x nU (ignored when nU == 0).  X_or_null: overrides the ctx's
+ * X for this call (the trace's :X => k => :X values; n x nX) or NULL to use gpslc_set_data's.
+ * Uses the ctx's T and Y.  S independent parameter sets are evaluated per call (S = 1 for one
+ * Gen `update`); U is n x nU x S, uyLS nU x S, xyLS nX x S, the rest length S. */
+int gpslc_y_logpdf(gpslc_ctx* ctx, int64_t S, const double* U, const double* X_or_null,
+                   const double* uyLS, const double* xyLS, const double* tyLS,
+                   const double* yScale, const double* yNoise, double* logpdf /* S */);
+
+/* ---- src/estimation.jl, src/driver.jl, src/prediction.jl ------------------------------ */
+
+/* The ensemble driver: everything sampleITE / sampleSATE / predictCounterfactualEffects
+ * (src/driver.jl:86-89, 108-111; src/prediction.jl:23-36) compute for S posterior samples
+ * (the rows extractParameters, src/utils.jl:92-124, would return for nBurnIn:stepSize:nOuter)
+ * and L intervention levels doT[0..L).
+ *
+ *   U       n x nU x S      uyLS  nU x S      xyLS  nX x S      tyLS, yScale, yNoise  S
+ *   pred_noise  = hyperparams.predictionCovarianceNoise (src/estimation.jl:82)
+ *
+ * Outputs (any may be NULL):
+ *   meanSATE, varSATE   S x L   (sample index fastest)   conditionalSATE, src/estimation.jl:116-121,
+ *                               of Symmetric(CovITE) + pred_noise*I (src/estimation.jl:82, 127-140)
+ *   meanITE             n x S x L                         conditionalITE mean, src/estimation.jl:46
+ *   ite_draws           L x n x (S*spp), level fastest    predictCounterfactualEffects' `ite`
+ *                               (src/prediction.jl:30-33); column order sample-outer/draw-inner
+ *                               (src/estimation.jl:100-107)
+ * Draws use z_or_null (n x spp x S x L standard normals: z[i + n*(d + spp*(s + S*l))]) when given,
+ * else the library's Philox4x32-10 + Box-Muller stream seeded by `seed` (documented in DESIGN.md,
+ * restated in oracle/gpslc_oracle.py: stream id = s + S*l, element = i + n*d). */
+int gpslc_predict(gpslc_ctx* ctx, int64_t S, const double* U, const double* uyLS,
+                  const double* xyLS, const double* tyLS, const double* yScale,
+                  const double* yNoise, int32_t L, const double* doT, double pred_noise,
+                  int32_t spp, uint64_t seed, const double* z_or_null,
+                  double* meanSATE, double* varSATE, double* meanITE, double* ite_draws);
+int gpslc_predict_dev(gpslc_ctx* ctx, int64_t S, const double* U, const double* uyLS,
+                      const double* xyLS, const double* tyLS, const double* yScale,
+                      const double* yNoise, int32_t L, const double* doT, double pred_noise,
+                      int32_t spp, uint64_t seed, const double* z_or_null,
+                      double* meanSATE, double* varSATE, double* meanITE, double* ite_draws);
+
+/* ITEDistributions(g, doT) (src/estimation.jl:66-86) for one intervention level, with the
+ * reference's output layout: MeanITEs S x n and CovITEs S x n x n, sample index fastest;
+ * CovITEs carries the + pred_noise*I of src/estimation.jl:82.  Either output may be NULL. */
+int gpslc_ite_distributions(gpslc_ctx* ctx, int64_t S, const double* U, const double* uyLS,
+                            const double* xyLS, const double* tyLS, const double* yScale,
+                            const double* yNoise, double doT, double pred_noise,
+                            double* MeanITEs, double* CovITEs);
+
+/* SATEsamples (src/estimation.jl:148-163): out[j*spp + d] = mean[j] + var[j] * z — the variance
+ * is used as the standard deviation, as the reference does (src/estimation.jl:159).  Host-only
+ * arithmetic; z_or_null (S*spp) or Philox stream `seed`, stream id 2^40 + j. */
+int gpslc_sate_samples(const double* meanSATE, const double* varSATE, int64_t S, int32_t spp,
+                       uint64_t seed, const double* z_or_null, double* out /* S*spp */);
+
+/* 1-based failing pivot (0 = ok) of every posterior sample of the last predict / y_logpdf /
+ * ite_distributions call; codes > n refer to the CovITE factorisation (pivot - n). */
+int gpslc_last_info(const gpslc_ctx* ctx, int32_t* info, int64_t S);
+
+/* ---- measurement hooks (bench.py, profiles/) ----------------------------------------- */
+
+/* Accumulated HIP-event statistics of the dominant kernel (the f64-MFMA tile update) since
+ * the last reset, recorded when the ctx was created with GPSLC_FLAG_PROFILE:
+ * launches, total device milliseconds, total algorithmic flop. */
+int gpslc_profile_reset(gpslc_ctx* ctx);
+int gpslc_profile_get(gpslc_ctx* ctx, int64_t* launches, double* total_ms, double* total_flop);
+
+/* library / build identification, e.g. "gpslc_hip 0.1 gfx950" */
+const char* gpslc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSLC_HIP_H */

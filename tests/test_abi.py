@@ -1,0 +1,52 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol the
+public header declares, and the binding table covers the header (no compute calls without a GPU)."""
+import ctypes
+import os
+
+import pytest
+
+import causalgpslc_jl_amd as gp
+from causalgpslc_jl_amd import _lib
+
+
+def test_header_and_binding_table_agree():
+    hdr = set(_lib.header_symbols())
+    assert hdr == set(_lib.SIGNATURES), (hdr ^ set(_lib.SIGNATURES))
+    assert len(hdr) >= 15
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "build the library first (python -c 'import __graft_entry__ as g; g.build()')"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _lib.header_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/gpslc_hip.h but not exported"
+    gp.load_library()
+    assert b"gfx950" in _lib.load().gpslc_version()
+
+
+def test_host_only_entry_point_sate_samples():
+    # gpslc_sate_samples is pure host arithmetic (src/estimation.jl:148-163): callable without a GPU
+    import numpy as np
+    out = gp.SATEsamples(np.array([1.0, 2.0]), np.array([0.25, 4.0]), 2, z=np.array([1.0, -1.0, 0.5, 2.0]))
+    assert np.allclose(out, [1.25, 0.75, 4.0, 10.0])
+    import gpslc_oracle as orc
+    out = gp.SATEsamples(np.array([0.0]), np.array([1.0]), 6, seed=99)
+    ref = orc.philox_normals(99, (1 << 40) + 0, 6)
+    assert np.allclose(out, ref, rtol=0, atol=1e-15)
+
+
+def test_argument_validation_mirrors_reference_asserts():
+    import numpy as np
+    with pytest.raises(AssertionError):   # src/kernel.jl:25 "X1 and X2 are different sizes!"
+        gp.rbfKernelLog(np.ones((3, 2)), np.ones((4, 2)), 1.0)
+    with pytest.raises(AssertionError):   # src/kernel.jl:14-16
+        gp.rbfKernelLog(np.ones((3, 2)), np.ones((3, 2)), np.ones(3))
+    with pytest.raises(ValueError):       # zero step: Julia's range constructor throws
+        gp.doTRange(1.0, 1.0, 10)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgpslc_hip.so")
+    with pytest.raises(_lib.GPSLCLibraryError):
+        _lib.load()
