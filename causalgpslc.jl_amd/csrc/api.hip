@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -56,13 +57,16 @@ struct gpslc_ctx {
     double *dX = nullptr, *dT = nullptr, *dY = nullptr;
     bool has_data = false;
     int max_batch = 0;   // 0 = auto
-    int panel = 2;
+    int panel = 8;
     int nstreams = 2;
     std::vector<hipStream_t> streams;
     std::vector<Arena> arenas;     // one per stream slot
     Arena scratch;                 // call-level buffers (host-pointer entry points, info, ...)
     std::string err;
     std::vector<int32_t> last_info;
+    // L2-blocked visiting orders of the lower-triangular tile sets, keyed by the triangle size m
+    std::vector<unsigned short*> tri_order;
+    int order_block = 8;
     // profiling of the dominant kernel
     std::vector<ProfRec> prof;
     size_t prof_used = 0;
@@ -113,7 +117,19 @@ void ensure_streams(gpslc_ctx* c) {
 }
 
 // ---- profiled launch of the accumulate-mode tile kernel ---------------------------------
-void gemm(gpslc_ctx* c, const GemmArgs& g, hipStream_t st) {
+void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
+    GemmArgs g = g0;
+    static const int dbg_m = getenv("GPSLC_GEMM_DBG") ? atoi(getenv("GPSLC_GEMM_DBG")) : 0;
+    static bool dbg_done = false;
+    unsigned long long* dbg_buf = nullptr;
+    size_t dbg_words = 0;
+    if (dbg_m > 0 && !dbg_done && g.shape == 0 && g.mi == dbg_m) {
+        dbg_words = (size_t)g.ntiles * g.nbatch * 8;
+        HC(hipMalloc((void**)&dbg_buf, dbg_words * 8));
+        HC(hipMemset(dbg_buf, 0, dbg_words * 8));
+        g.dbg = dbg_buf;
+        dbg_done = true;
+    }
     if (g.ntiles <= 0 || g.nbatch <= 0 || (g.k1 <= g.k0 && g.accumulate)) return;
     const bool prof = (c->flags & GPSLC_FLAG_PROFILE) && g.accumulate;
     if (prof) {
@@ -132,6 +148,14 @@ void gemm(gpslc_ctx* c, const GemmArgs& g, hipStream_t st) {
     } else {
         launch_tile_gemm(g, st);
     }
+    if (dbg_buf) {
+        HC(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h(dbg_words);
+        HC(hipMemcpy(h.data(), dbg_buf, dbg_words * 8, hipMemcpyDeviceToHost));
+        FILE* f = fopen("gpurun_out/gemm_dbg.bin", "wb");
+        if (f) { fwrite(h.data(), 8, dbg_words, f); fclose(f); }
+        (void)hipFree(dbg_buf);
+    }
 }
 
 void prof_collect(gpslc_ctx* c) {
@@ -144,6 +168,32 @@ void prof_collect(gpslc_ctx* c) {
         }
     }
     c->prof_used = 0;
+}
+
+// Visiting order of the m(m+1)/2 lower-triangular output tiles: G x G super-blocks in row-major order,
+// row-major inside.  The kernel hands XCD x the x-th contiguous run of work items, so the ~64
+// workgroups an XCD runs concurrently cover about one super-block: they walk the K slabs of the same
+// G + G operand tile rows together and share them in that XCD's L2 instead of each streaming its own
+// copy from HBM (operand traffic / ~G).
+const unsigned short* tri_order(gpslc_ctx* c, int m) {
+    const int G = c->order_block;
+    if (G <= 1 || m <= 2) return nullptr;
+    if ((int)c->tri_order.size() <= m) c->tri_order.resize(m + 1, nullptr);
+    if (c->tri_order[m]) return c->tri_order[m];
+    std::vector<unsigned short> h;
+    h.reserve((size_t)m * (m + 1));
+    for (int I = 0; I < m; I += G)
+        for (int J = 0; J <= I; J += G)
+            for (int i = I; i < std::min(I + G, m); ++i)
+                for (int j = J; j < std::min(J + G, m) && j <= i; ++j) {
+                    h.push_back((unsigned short)i);
+                    h.push_back((unsigned short)j);
+                }
+    unsigned short* d = nullptr;
+    HC(hipMalloc((void**)&d, h.size() * sizeof(unsigned short)));
+    HC(hipMemcpy(d, h.data(), h.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    c->tri_order[m] = d;
+    return d;
 }
 
 TRef lower_ref(double* base, long long bstride) { return TRef{base, bstride, 0, 0, 0, 0}; }
@@ -181,6 +231,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             const int m = ntot - kend;
             g.shape = 0; g.i0 = kend; g.j0 = kend; g.mi = m; g.mj = m;
             g.k0 = ka; g.k1 = kend; g.accumulate = 1; g.nbatch = nb; g.ntiles = m * (m + 1) / 2;
+            g.order = tri_order(c, m);
             gemm(c, g, st);
         }
     }
@@ -204,7 +255,9 @@ struct PredictIO {
 };
 
 int auto_batch(gpslc_ctx* c, int64_t S, size_t per_sample_bytes, size_t fixed_bytes) {
-    long long b = 32768LL / ((long long)c->nt * c->nt);
+    // enough matrices in flight that the per-step diagonal-block kernel (one workgroup per matrix) and the
+    // launch quantisation of the late, small trailing updates are amortised: 256 at N = 4096
+    long long b = 262144LL / ((long long)c->nt * c->nt);
     b = std::max<long long>(32, std::min<long long>(b, 4096));
     if (c->max_batch > 0) b = c->max_batch;
     size_t free_b = 0, tot_b = 0;
@@ -364,6 +417,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io) {
                         g.A = W; g.B = W; g.C = Cm;
                         g.shape = 0; g.i0 = 0; g.j0 = 0; g.mi = nt; g.mj = nt;
                         g.k0 = 0; g.k1 = nt; g.accumulate = 1; g.nbatch = ub; g.ntiles = (int)nlow;
+                        g.order = tri_order(c, nt);
                         gemm(c, g, st);
                     }
                     if (want_cov) {
@@ -490,6 +544,7 @@ int gpslc_create(gpslc_ctx** out, int device, int64_t n, int32_t nX, int32_t nU,
     if (!c) return GPSLC_ERR_NOMEM;
     c->device = device; c->n = n; c->nX = nX; c->nU = nU; c->flags = flags;
     c->nt = (int)((n + GP_TS - 1) / GP_TS);
+    if (getenv("GPSLC_ORDER_BLOCK")) c->order_block = atoi(getenv("GPSLC_ORDER_BLOCK"));
     int rc = guarded(c, [&]() {
         hipDeviceProp_t prop;
         HC(hipGetDeviceProperties(&prop, device));
@@ -516,6 +571,7 @@ int gpslc_destroy(gpslc_ctx* c) {
     for (auto& a : c->arenas) if (a.base) (void)hipFree(a.base);
     if (c->scratch.base) (void)hipFree(c->scratch.base);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto p : c->tri_order) if (p) (void)hipFree(p);
     if (c->dX) (void)hipFree(c->dX);
     if (c->dT) (void)hipFree(c->dT);
     if (c->dY) (void)hipFree(c->dY);

@@ -40,6 +40,8 @@ struct GemmArgs {
     int accumulate;   // 1: C -= A B^T, 0: C = A B^T
     int nbatch;
     int ntiles;       // output tiles per batch element
+    const unsigned short* order;  // optional (ii, jj) pairs: output-tile visiting order (L2-blocked), or null
+    unsigned long long* dbg;      // diagnostic builds only: per-workgroup s_memtime stamps, or null
 };
 
 // per-posterior-sample inputs of the Gram build (device pointers, already offset to sample 0 of the call)

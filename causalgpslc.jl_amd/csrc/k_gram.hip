@@ -8,6 +8,7 @@
 //   epilogue           Schur complement of the augmented block -> MeanSATE, VarSATE, logdet, quad.
 //   rbf_log / process_cov  the two src/kernel.jl entry points as stand-alone dense kernels.
 #include "gpslc_internal.h"
+#include "gp_math.h"
 
 #define MAXF 32   // max nU + nX handled by the fused Gram kernel
 
@@ -28,12 +29,11 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /* >= 4 do
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = g.nU + g.nX;
-    double* fr = sm;                     // [F][128] row-block features
-    double* fc = fr + MAXF * GP_TS;      // [F][128] column-block features
-    double* tr = fc + MAXF * GP_TS;      // [128] T of row block
+    double* fr = sm;                     // [F][128] row-block features, pre-scaled by 1/LS
+    double* fc = fr + F * GP_TS;         // [F][128] column-block features, pre-scaled by 1/LS
+    double* tr = fc + F * GP_TS;         // [128] T of row block
     double* tc = tr + GP_TS;             // [128]
-    double* wf = tc + GP_TS;             // [MAXF] 1 / LS^2
-    double* red = wf + MAXF;             // [4][128][2] cross-wave row-sum staging
+    double* red = tc + GP_TS;            // [4][128][2] cross-wave row-sum staging
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -49,23 +49,20 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     const int n = g.n;
     const int gi0 = ti * GP_TS, gj0 = tj * GP_TS;
 
-    // stage features (zeros on the padding)
+    // stage features scaled by 1/LS (zeros on the padding): (x - x')^2 / LS^2 = (x/LS - x'/LS)^2
     for (int idx = tid; idx < F * GP_TS; idx += 256) {
         const int f = idx >> 7, r = idx & 127;
-        const double* src; long long ld;
-        if (f < g.nU) { src = g.p.U + (s * g.nU + f) * (long long)n; ld = 0; }
-        else { src = g.X + (long long)(f - g.nU) * n; ld = 0; }
-        (void)ld;
-        fr[f * GP_TS + r] = (gi0 + r < n) ? src[gi0 + r] : 0.0;
-        fc[f * GP_TS + r] = (gj0 + r < n) ? src[gj0 + r] : 0.0;
+        const double* src;
+        double l;
+        if (f < g.nU) { src = g.p.U + (s * g.nU + f) * (long long)n; l = g.p.uyLS[s * g.nU + f]; }
+        else { src = g.X + (long long)(f - g.nU) * n; l = g.p.xyLS[s * g.nX + (f - g.nU)]; }
+        const double il = 1.0 / l;
+        fr[f * GP_TS + r] = (gi0 + r < n) ? src[gi0 + r] * il : 0.0;
+        fc[f * GP_TS + r] = (gj0 + r < n) ? src[gj0 + r] * il : 0.0;
     }
     if (tid < GP_TS) {
         tr[tid] = (gi0 + tid < n) ? g.T[gi0 + tid] : 0.0;
         tc[tid] = (gj0 + tid < n) ? g.T[gj0 + tid] : 0.0;
-    }
-    if (tid < F) {
-        const double l = (tid < g.nU) ? g.p.uyLS[s * g.nU + tid] : g.p.xyLS[s * g.nX + (tid - g.nU)];
-        wf[tid] = 1.0 / (l * l);
     }
     __syncthreads();
 
@@ -97,12 +94,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) lux[p] = 0.0;
         for (int f = 0; f < F; ++f) {
-            const double w = wf[f];
             const double c = fc[f * GP_TS + cq];
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const double d = fr[f * GP_TS + ty + 16 * p] - c;
-                lux[p] += (d * d) * w;
+                lux[p] = fma(d, d, lux[p]);
             }
         }
         const double tcq = tc[cq];
@@ -112,8 +108,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
             const int rp = ty + 16 * p;
             const int gi = gi0 + rp;
             const double dt = tra[p] - tcq;
-            double Bv = ys * exp(-lux[p]);
-            double Ev = exp(-((dt * dt) * wt));
+            double Bv = ys * gp_exp_neg(-lux[p]);
+            double Ev = gp_exp_neg(-((dt * dt) * wt));
             double Kv = Bv * Ev;
             double Av = Kv;
             const bool inside = (gi < n) && (gj < n);
@@ -160,17 +156,17 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     }
 }
 
-#define GRAM_LDS_BYTES ((2 * MAXF * GP_TS + 2 * GP_TS + MAXF + 4 * GP_TS * 2) * 8)
+#define GRAM_LDS_BYTES(F) ((2 * (F) * GP_TS + 2 * GP_TS + 4 * GP_TS * 2) * 8)
 
 void launch_gram(const GramArgs& g, int nbatch, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GRAM_LDS_BYTES);
+                                  GRAM_LDS_BYTES(MAXF));
         attr_set = true;
     }
     const int nlow = g.nt * (g.nt + 1) / 2;
-    hipLaunchKernelGGL(gram_kernel, dim3(nlow, nbatch), dim3(256), GRAM_LDS_BYTES, st, g);
+    hipLaunchKernelGGL(gram_kernel, dim3(nlow, nbatch), dim3(256), GRAM_LDS_BYTES(g.nU + g.nX), st, g);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -207,7 +203,7 @@ __global__ __launch_bounds__(256) void rhs_prepare_kernel(RhsArgs a) {
         for (int j = tid; j < Np; j += 256) {
             // same thread -> j assignment and the same tree as btot, so r == 1 reproduces btot bit for bit
             const double dt = (j < a.n ? a.T[j] : 0.0) - dot;
-            const double r = exp(-((dt * dt) * wt));
+            const double r = gp_exp_neg(-((dt * dt) * wt));
             acc += r * bs[j];
         }
         const double rb = block_sum_256(acc, red);
@@ -243,7 +239,7 @@ __global__ __launch_bounds__(256) void rhs_tiles_kernel(RhsArgs a) {
             if (gq == 0) v = a.Y[gj];
             else if (gq <= a.L) {
                 const double dt = a.T[gj] - a.doT[gq - 1];
-                const double r = exp(-((dt * dt) * wt));
+                const double r = gp_exp_neg(-((dt * dt) * wt));
                 v = r * bs[gj] - ks[gj];
             }
         }

@@ -1,6 +1,7 @@
 // O(N^2) kernels around the factor: back-substitution for alpha = A^-1 Y, the MeanITE pass,
 // construction of D / Delta for the full ITE covariance, CovITE gather and the predictive draws.
 #include "gpslc_internal.h"
+#include "gp_math.h"
 
 #define MAXF 32
 
@@ -10,6 +11,26 @@
 // of them); workgroup k == i publishes alpha_i, workgroups k < i update z_k -= L(i,k)^T alpha_i.
 // z_i is only read in launch i, so there is no intra-launch hazard.
 // ---------------------------------------------------------------------------------------
+// (t^T v)_c for the 32 columns c = wave*32 .. +31 of a column-major 128 x 128 tile: every lane loads its
+// two rows of all 32 columns first (64 independent 8-byte loads in flight), then the wave reduces.
+__device__ __forceinline__ void tile_tv32(const double* __restrict__ t, const double* v /*LDS[128]*/,
+                                          int wave, int lane, double out[32]) {
+    const double v0 = v[lane], v1 = v[lane + 64];
+    double p[32];
+#pragma unroll
+    for (int cc = 0; cc < 32; ++cc) {
+        const double* col = t + (wave * 32 + cc) * GP_TS;
+        p[cc] = col[lane] * v0 + col[lane + 64] * v1;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 32; ++cc) {
+        double x = p[cc];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+        out[cc] = x;
+    }
+}
+
 __global__ __launch_bounds__(256) void backsolve_step_kernel(BackArgs a, int i, double* alpha) {
     __shared__ double zi[GP_TS];
     __shared__ double ai[GP_TS];
@@ -21,26 +42,21 @@ __global__ __launch_bounds__(256) void backsolve_step_kernel(BackArgs a, int i, 
     if (tid < GP_TS) zi[tid] = z[i * GP_TS + tid];
     __syncthreads();
     const double* invt = a.inv + b * a.inv_bstride + (long long)i * GP_TSQ;
-    // (inv^T z)_c = sum_r inv[r][c] z[r]; wave w handles columns w*32 .. w*32+31, lanes stride r
-    for (int cc = 0; cc < 32; ++cc) {
-        const int c = wave * 32 + cc;
-        double v = invt[c * GP_TS + lane] * zi[lane] + invt[c * GP_TS + lane + 64] * zi[lane + 64];
+    double o32[32];
+    tile_tv32(invt, zi, wave, lane, o32);
+    if (lane == 0) {
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) ai[c] = v;
+        for (int cc = 0; cc < 32; ++cc) ai[wave * 32 + cc] = o32[cc];
     }
     __syncthreads();
     if (k == i) {
         if (tid < GP_TS) alpha[b * Np + i * GP_TS + tid] = ai[tid];
         return;
     }
-    const double* t = tref_tile(a.M, b, i, k);
-    for (int cc = 0; cc < 32; ++cc) {
-        const int c = wave * 32 + cc;
-        double v = t[c * GP_TS + lane] * ai[lane] + t[c * GP_TS + lane + 64] * ai[lane + 64];
+    tile_tv32(tref_tile(a.M, b, i, k), ai, wave, lane, o32);
+    if (lane == 0) {
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) z[k * GP_TS + c] -= v;
+        for (int cc = 0; cc < 32; ++cc) z[k * GP_TS + wave * 32 + cc] -= o32[cc];
     }
 }
 
@@ -65,17 +81,15 @@ void launch_backsolve(const BackArgs& a, int nbatch, hipStream_t st) {
 // D = Ks' - K formed element-wise so that doT == T gives exact zeros, test/estimation.jl:6-66).
 // One workgroup per (row block, sample); levels are processed LC at a time.
 // ---------------------------------------------------------------------------------------
-#define LC 16
+template <int FREG, int LCT>
 __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = a.nU + a.nX;
-    double* fr = sm;                       // [MAXF][128]
-    double* fc = fr + MAXF * GP_TS;        // [MAXF][128]
-    double* tcs = fc + MAXF * GP_TS;       // [128]
+    double* fc = sm;                       // [FREG][128] column-block features / LS (zero rows beyond F)
+    double* tcs = fc + FREG * GP_TS;       // [128]
     double* al = tcs + GP_TS;              // [128]
-    double* rl = al + GP_TS;               // [LC][128]
-    double* wf = rl + LC * GP_TS;          // [MAXF]
-    double* red = wf + MAXF;               // [128][LC]
+    double* rl = al + GP_TS;               // [LCT][128]
+    double* red = rl + LCT * GP_TS;        // [128][LCT]
     const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;
     const int ib = blockIdx.x;
     const long long b = blockIdx.y, s = a.s0 + b;
@@ -85,90 +99,102 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     auto feat_src = [&](int f) -> const double* {
         return (f < a.nU) ? a.p.U + (s * a.nU + f) * (long long)n : a.X + (long long)(f - a.nU) * n;
     };
-    for (int idx = tid; idx < F * GP_TS; idx += 256) {
-        const int f = idx >> 7, rr = idx & 127;
-        const int g = ib * GP_TS + rr;
-        fr[idx] = (g < n) ? feat_src(f)[g] : 0.0;
-    }
-    if (tid < F) {
-        const double l = (tid < a.nU) ? a.p.uyLS[s * a.nU + tid] : a.p.xyLS[s * a.nX + (tid - a.nU)];
-        wf[tid] = 1.0 / (l * l);
-    }
+    auto feat_il = [&](int f) -> double {
+        return 1.0 / ((f < a.nU) ? a.p.uyLS[s * a.nU + f] : a.p.xyLS[s * a.nX + (f - a.nU)]);
+    };
+    double af[FREG];   // this thread's row features / LS
+#pragma unroll
+    for (int f = 0; f < FREG; ++f) af[f] = (f < F && gi < n) ? feat_src(f)[gi] * feat_il(f) : 0.0;
     const double ys = a.p.yScale[s];
     const double tl = a.p.tyLS[s];
     const double wt = 1.0 / (tl * tl);
     const double tri = (gi < n) ? a.T[gi] : 0.0;
     const double* alpha = a.alpha + b * Np;
 
-    for (int l0 = 0; l0 < a.L; l0 += LC) {
-        const int nl = min(LC, a.L - l0);
-        double acc[LC];
+    for (int l0 = 0; l0 < a.L; l0 += LCT) {
+        const int nl = min(LCT, a.L - l0);
+        double acc[LCT];
 #pragma unroll
-        for (int ll = 0; ll < LC; ++ll) acc[ll] = 0.0;
+        for (int ll = 0; ll < LCT; ++ll) acc[ll] = 0.0;
         for (int jt = 0; jt < a.nt; ++jt) {
             __syncthreads();
-            for (int idx = tid; idx < F * GP_TS; idx += 256) {
+            for (int idx = tid; idx < FREG * GP_TS; idx += 256) {
                 const int f = idx >> 7, cc = idx & 127;
                 const int g = jt * GP_TS + cc;
-                fc[idx] = (g < n) ? feat_src(f)[g] : 0.0;
+                fc[idx] = (f < F && g < n) ? feat_src(f)[g] * feat_il(f) : 0.0;
             }
             if (tid < GP_TS) {
                 const int g = jt * GP_TS + tid;
                 tcs[tid] = (g < n) ? a.T[g] : 0.0;
                 al[tid] = (g < n) ? alpha[g] : 0.0;
             }
-            for (int idx = tid; idx < LC * GP_TS; idx += 256) {
+            for (int idx = tid; idx < LCT * GP_TS; idx += 256) {
                 const int ll = idx >> 7, cc = idx & 127;
                 const int g = jt * GP_TS + cc;
                 double v = 0.0;
                 if (ll < nl && g < n) {
                     const double dt = a.T[g] - a.doT[l0 + ll];
-                    v = exp(-((dt * dt) * wt));
+                    v = gp_exp_neg(-((dt * dt) * wt));
                 }
                 rl[idx] = v;
             }
             __syncthreads();
-#pragma unroll 1
+#pragma unroll 2
             for (int cq = 0; cq < 64; ++cq) {
                 const int c = h * 64 + cq;
                 double lux = 0.0;
-                for (int f = 0; f < F; ++f) {
-                    const double d = fr[f * GP_TS + r] - fc[f * GP_TS + c];
-                    lux += (d * d) * wf[f];
+#pragma unroll
+                for (int f = 0; f < FREG; ++f) {
+                    const double d = af[f] - fc[f * GP_TS + c];
+                    lux = fma(d, d, lux);
                 }
                 const double dt = tri - tcs[c];
-                const double Bv = ys * exp(-lux);
-                const double Ev = exp(-((dt * dt) * wt));
+                const double Bv = ys * gp_exp_neg(-lux);
+                const double Ev = gp_exp_neg(-((dt * dt) * wt));
                 const double ba = Bv * al[c];
 #pragma unroll
-                for (int ll = 0; ll < LC; ++ll) acc[ll] += ba * (rl[ll * GP_TS + c] - Ev);
+                for (int ll = 0; ll < LCT; ++ll) acc[ll] = fma(ba, rl[ll * GP_TS + c] - Ev, acc[ll]);
             }
         }
         __syncthreads();
         if (h == 1) {
 #pragma unroll
-            for (int ll = 0; ll < LC; ++ll) red[r * LC + ll] = acc[ll];
+            for (int ll = 0; ll < LCT; ++ll) red[r * LCT + ll] = acc[ll];
         }
         __syncthreads();
         if (h == 0 && gi < n) {
 #pragma unroll
-            for (int ll = 0; ll < LC; ++ll)
+            for (int ll = 0; ll < LCT; ++ll)
                 if (ll < nl)
                     a.meanITE[(long long)gi * a.si + s * a.ss + (long long)(l0 + ll) * a.sl] =
-                        acc[ll] + red[r * LC + ll];
+                        acc[ll] + red[r * LCT + ll];
         }
     }
 }
-#define ITEMEAN_LDS_BYTES ((2 * MAXF * GP_TS + 2 * GP_TS + LC * GP_TS + MAXF + GP_TS * LC) * 8)
 
-void launch_ite_mean(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+template <int FREG, int LCT>
+static void launch_ite_mean_t(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+    const int bytes = (FREG * GP_TS + 2 * GP_TS + 2 * LCT * GP_TS) * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ite_mean_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, ITEMEAN_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)ite_mean_kernel<FREG, LCT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ite_mean_kernel, dim3(a.nt, nbatch), dim3(256), ITEMEAN_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((ite_mean_kernel<FREG, LCT>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
+}
+template <int FREG>
+static void launch_ite_mean_f(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+    if (a.L <= 1) launch_ite_mean_t<FREG, 1>(a, nbatch, st);
+    else if (a.L <= 4) launch_ite_mean_t<FREG, 4>(a, nbatch, st);
+    else launch_ite_mean_t<FREG, 16>(a, nbatch, st);
+}
+void launch_ite_mean(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+    const int F = a.nU + a.nX;
+    if (F <= 4) launch_ite_mean_f<4>(a, nbatch, st);
+    else if (F <= 12) launch_ite_mean_f<12>(a, nbatch, st);
+    else if (F <= 20) launch_ite_mean_f<20>(a, nbatch, st);
+    else launch_ite_mean_f<32>(a, nbatch, st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -180,12 +206,11 @@ __global__ __launch_bounds__(256) void dt_build_kernel(DtArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = a.nU + a.nX;
     double* fr = sm;
-    double* fc = fr + MAXF * GP_TS;
-    double* tr = fc + MAXF * GP_TS;
+    double* fc = fr + F * GP_TS;
+    double* tr = fc + F * GP_TS;
     double* tc = tr + GP_TS;
     double* rr_ = tc + GP_TS;   // r_i of the row block
     double* rc_ = rr_ + GP_TS;  // r_j of the column block
-    double* wf = rc_ + GP_TS;
     const int tid = threadIdx.x;
     const int ti = blockIdx.x / a.nt, tj = blockIdx.x % a.nt;
     const long long b = blockIdx.y, s = a.s0 + b;
@@ -197,20 +222,17 @@ __global__ __launch_bounds__(256) void dt_build_kernel(DtArgs a) {
         const int f = idx >> 7, r = idx & 127;
         const double* src = (f < a.nU) ? a.p.U + (s * a.nU + f) * (long long)n
                                        : a.X + (long long)(f - a.nU) * n;
-        fr[idx] = (gi0 + r < n) ? src[gi0 + r] : 0.0;
-        fc[idx] = (gj0 + r < n) ? src[gj0 + r] : 0.0;
+        const double il = 1.0 / ((f < a.nU) ? a.p.uyLS[s * a.nU + f] : a.p.xyLS[s * a.nX + (f - a.nU)]);
+        fr[idx] = (gi0 + r < n) ? src[gi0 + r] * il : 0.0;
+        fc[idx] = (gj0 + r < n) ? src[gj0 + r] * il : 0.0;
     }
     if (tid < GP_TS) {
         const double t1 = (gi0 + tid < n) ? a.T[gi0 + tid] : 0.0;
         const double t2 = (gj0 + tid < n) ? a.T[gj0 + tid] : 0.0;
         tr[tid] = t1; tc[tid] = t2;
         const double d1 = t1 - a.doT, d2 = t2 - a.doT;
-        rr_[tid] = exp(-((d1 * d1) * wt));
-        rc_[tid] = exp(-((d2 * d2) * wt));
-    }
-    if (tid < F) {
-        const double l = (tid < a.nU) ? a.p.uyLS[s * a.nU + tid] : a.p.xyLS[s * a.nX + (tid - a.nU)];
-        wf[tid] = 1.0 / (l * l);
+        rr_[tid] = gp_exp_neg(-((d1 * d1) * wt));
+        rc_[tid] = gp_exp_neg(-((d2 * d2) * wt));
     }
     __syncthreads();
     const double ys = a.p.yScale[s];
@@ -225,12 +247,11 @@ __global__ __launch_bounds__(256) void dt_build_kernel(DtArgs a) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) lux[p] = 0.0;
         for (int f = 0; f < F; ++f) {
-            const double w = wf[f];
             const double c = fc[f * GP_TS + cq];
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const double d = fr[f * GP_TS + ty + 16 * p] - c;
-                lux[p] += (d * d) * w;
+                lux[p] = fma(d, d, lux[p]);
             }
         }
         const double tcq = tc[cq], rj = rc_[cq];
@@ -239,8 +260,8 @@ __global__ __launch_bounds__(256) void dt_build_kernel(DtArgs a) {
             const int rp = ty + 16 * p;
             const int gi = gi0 + rp;
             const double dt = tr[rp] - tcq;
-            const double Bv = ys * exp(-lux[p]);
-            const double Ev = exp(-((dt * dt) * wt));
+            const double Bv = ys * gp_exp_neg(-lux[p]);
+            const double Ev = gp_exp_neg(-((dt * dt) * wt));
             const double ri = rr_[rp];
             double Dv = Bv * (rj - Ev);
             double Cv = Bv * (((Ev - ri) - rj) + 1.0);
@@ -252,16 +273,16 @@ __global__ __launch_bounds__(256) void dt_build_kernel(DtArgs a) {
         }
     }
 }
-#define DT_LDS_BYTES ((2 * MAXF * GP_TS + 4 * GP_TS + MAXF) * 8)
+#define DT_LDS_BYTES(F) ((2 * (F) * GP_TS + 4 * GP_TS) * 8)
 
 void launch_dt_build(const DtArgs& a, int nbatch, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)dt_build_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS_BYTES);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS_BYTES(MAXF));
         attr_set = true;
     }
-    hipLaunchKernelGGL(dt_build_kernel, dim3(a.nt * a.nt, nbatch), dim3(256), DT_LDS_BYTES, st, a);
+    hipLaunchKernelGGL(dt_build_kernel, dim3(a.nt * a.nt, nbatch), dim3(256), DT_LDS_BYTES(a.nU + a.nX), st, a);
 }
 
 // CovITEs[s + S*(i + n*j)] (src/estimation.jl:75, :82 layout: sample index fastest), both triangles

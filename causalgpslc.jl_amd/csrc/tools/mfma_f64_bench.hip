@@ -26,17 +26,41 @@ __global__ void layout_kernel(const double* A /*16x4 row-major*/, const double* 
 }
 
 template <int NACC>
-__global__ __launch_bounds__(256) void rate_kernel(double* out, int iters, double seed) {
+__global__ __launch_bounds__(256) void rate_kernel(double* out, int iters, double seed, unsigned long long* clk) {
     d4 acc[NACC];
     for (int i = 0; i < NACC; ++i) acc[i] = (d4){seed, 0.0, seed, 1.0};
     double a = seed + threadIdx.x * 1e-3, b = seed - threadIdx.x * 1e-3;
-    for (int it = 0; it < iters; ++it) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    // 32 x NACC MFMAs per trip so that the compiler's accumulator shuffling at the loop back-edge
+    // (v_accvgpr moves) is amortised to < 1 % of the issue slots
+    for (int it = 0; it < iters; it += 32) {
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int u = 0; u < 32; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     double s = 0;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+// plain vector FMA rate for comparison (spec: vector fp64 = matrix fp64 = 78.6 TF)
+__global__ __launch_bounds__(256) void valu_kernel(double* out, int iters, double seed, unsigned long long* clk) {
+    double x[16];
+    for (int i = 0; i < 16; ++i) x[i] = seed + i + threadIdx.x * 1e-6;
+    const double a = 1.0000001, b = 1e-9;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = __builtin_fma(x[i], a, b);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+    for (int i = 0; i < 16; ++i) s += x[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
 int main() {
@@ -70,20 +94,52 @@ int main() {
     const int cus = prop.multiProcessorCount;
     double* dout; HC(hipMalloc(&dout, (size_t)cus * 8 * 256 * 8));
     hipEvent_t e_a, e_b; HC(hipEventCreate(&e_a)); HC(hipEventCreate(&e_b));
-    for (int wpc = 1; wpc <= 2; ++wpc) {
+    unsigned long long* dclk; HC(hipMalloc(&dclk, 16));
+    unsigned long long hclk[2];
+    for (int wpc = 1; wpc <= 4; wpc *= 2) {
         const int blocks = cus * wpc;   // 256-thread blocks: wpc waves per SIMD
-        const int iters = 20000;
-        for (int rep = 0; rep < 3; ++rep) {
+        const int iters = 20480;
+        for (int rep = 0; rep < 2; ++rep) {
             HC(hipEventRecord(e_a));
-            hipLaunchKernelGGL(rate_kernel<8>, dim3(blocks), dim3(256), 0, 0, dout, iters, 1.0 + rep);
+            hipLaunchKernelGGL(rate_kernel<8>, dim3(blocks), dim3(256), 0, 0, dout, iters, 1.0 + rep, dclk);
             HC(hipEventRecord(e_b));
             HC(hipEventSynchronize(e_b));
             float ms; HC(hipEventElapsedTime(&ms, e_a, e_b));
+            HC(hipMemcpy(hclk, dclk, 16, hipMemcpyDeviceToHost));
+            const double ghz = (double)hclk[0] / (double)hclk[1] * 0.1;
             const double flop = (double)blocks * 4 /*waves*/ * iters * 8 * 2.0 * 16 * 16 * 4;
-            const double cyc = (ms * 1e-3) * 2.4e9 / ((double)iters * 8 * wpc);
-            printf("rate: %d CUs, %d wave/SIMD, 8 acc: %.2f ms  %.2f TFLOP/s  (~%.1f cycles/MFMA/SIMD at 2.4 GHz)\n",
-                   cus, wpc, ms, flop / (ms * 1e-3) / 1e12, cyc);
+            const double cyc = (double)hclk[0] / ((double)iters * 8 * wpc);
+            printf("mfma_f64_16x16x4: %d CUs, %d wave/SIMD, 8 acc: %.2f ms  %.2f TFLOP/s  in-kernel clock %.2f GHz, %.1f cycles/MFMA/SIMD\n",
+                   cus, wpc, ms, flop / (ms * 1e-3) / 1e12, ghz, cyc);
         }
+    }
+    for (int sub = 0; sub < 2; ++sub) {   // a subset of the CUs: is the rate chip-power limited?
+        const int blocks = sub == 0 ? 32 : 128;
+        const int iters = 20480;
+        HC(hipEventRecord(e_a));
+        hipLaunchKernelGGL(rate_kernel<8>, dim3(blocks), dim3(256), 0, 0, dout, iters, 1.5, dclk);
+        HC(hipEventRecord(e_b));
+        HC(hipEventSynchronize(e_b));
+        float ms; HC(hipEventElapsedTime(&ms, e_a, e_b));
+        HC(hipMemcpy(hclk, dclk, 16, hipMemcpyDeviceToHost));
+        const double flop = (double)blocks * 4 * iters * 8 * 2.0 * 16 * 16 * 4;
+        printf("mfma_f64_16x16x4: only %d blocks (1 wave/SIMD): %.2f ms %.2f TFLOP/s = %.3f TF per CU, clock %.2f GHz, %.1f cycles/MFMA\n",
+               blocks, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / blocks,
+               (double)hclk[0] / (double)hclk[1] * 0.1, (double)hclk[0] / ((double)iters * 8));
+    }
+    for (int wpc = 1; wpc <= 4; wpc *= 2) {
+        const int blocks = cus * wpc;
+        const int iters = 40000;
+        HC(hipEventRecord(e_a));
+        hipLaunchKernelGGL(valu_kernel, dim3(blocks), dim3(256), 0, 0, dout, iters, 1.0, dclk);
+        HC(hipEventRecord(e_b));
+        HC(hipEventSynchronize(e_b));
+        float ms; HC(hipEventElapsedTime(&ms, e_a, e_b));
+        HC(hipMemcpy(hclk, dclk, 16, hipMemcpyDeviceToHost));
+        const double flop = (double)blocks * 256 * iters * 16 * 2.0;
+        printf("v_fma_f64: %d wave/SIMD: %.2f ms  %.2f TFLOP/s  clock %.2f GHz, %.2f cycles per wave-FMA per SIMD\n", wpc, ms,
+               flop / (ms * 1e-3) / 1e12, (double)hclk[0] / (double)hclk[1] * 0.1,
+               (double)hclk[0] / ((double)iters * 16 * wpc));
     }
     return 0;
 }

@@ -139,31 +139,35 @@ def test_same_tuning_is_bitwise_reproducible(gp):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("pred_noise", [1e-10, 1e-3])
 @pytest.mark.parametrize("n,shape,bt", [(24, "UX", False), (150, "U", True), (200, "UX", False)])
-def test_ite_draws_with_supplied_normals(gp, n, shape, bt):
+def test_ite_draws_with_supplied_normals(gp, n, shape, bt, pred_noise):
+    """sampleITE with the caller's standard normals against the oracle (src/estimation.jl:95-109).
+
+    With the reference's default jitter (1e-10, src/hyperparameters.jl:92) CovITE + 1e-10 I is barely
+    positive definite (cond ~ 1e10): forming it carries an absolute error ~ 1e-14 (cancellation of O(1)
+    terms), i.e. a relative perturbation ~ 1e-4 of its smallest eigenvalues, and the Cholesky factor
+    moves by about that much in those directions — for ANY implementation, the reference's own LAPACK
+    path included.  So at 1e-10 the draws are compared to 1e-3 relative (norm-wise); with a jitter of
+    1e-3 (cond ~ 1e3) the same comparison is tight (1e-8)."""
     c = cases.make_case(n, shape, bt, S=2, seed=40 + n)
     spp = 3
     rng = np.random.default_rng(n)
     smp = cases.samples_of(c)
-    obj = cases.gpslc_object(gp, c)
+    obj = cases.gpslc_object(gp, c, hyperparams=gp.HyperParameters(predictionCovarianceNoise=pred_noise))
     doT = c["doTs"][1]
     z = rng.standard_normal((n, c["S"] * spp))
-    ref = orc.sample_ite(smp, c["X"], c["T"], c["Y"], doT, spp, z)
+    ref = orc.sample_ite(smp, c["X"], c["T"], c["Y"], doT, spp, z, pred_noise)
     out = gp.sampleITE(obj, doT, samplesPerPosterior=spp, z=z)
     assert out.shape == ref.shape
-    M, Cv = orc.ite_distributions(smp, c["X"], c["T"], c["Y"], doT)
+    M, _ = orc.ite_distributions(smp, c["X"], c["T"], c["Y"], doT, pred_noise)
+    rel = 1e-3 if pred_noise < 1e-6 else 1e-8
     for s in range(c["S"]):
-        # CovITE + 1e-10 I is barely positive definite: its factor is only determined up to
-        # cond * eps, so draws are compared through their defining property instead of entry-wise:
-        # (draw - mean) must equal L z for SOME factor L L' = Cov  <=>  the Mahalanobis form matches
-        Lr = np.linalg.cholesky(Cv[s])
         for d in range(spp):
             col = s * spp + d
             dev_out = out[:, col] - M[s]
             dev_ref = ref[:, col] - M[s]
-            tol = 1e-8 * np.linalg.norm(Lr, 2) * np.linalg.norm(z[:, col])
-            # entry-wise agreement holds for the well-conditioned leading part; report the norm-wise bound
-            assert np.linalg.norm(dev_out - dev_ref) <= max(tol, 2e-5 * np.linalg.norm(dev_ref) + 1e-9)
+            assert np.linalg.norm(dev_out - dev_ref) <= rel * np.linalg.norm(dev_ref) + 1e-12
 
 
 def test_predict_counterfactual_effects_shape_and_levels(gp):
