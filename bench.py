@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--nu", type=int, default=2)
     ap.add_argument("--levels", type=int, default=1)
-    ap.add_argument("--samples-per-step", type=int, default=128)
+    ap.add_argument("--samples-per-step", type=int, default=512)
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)

@@ -12,3 +12,4 @@ from .api import (  # noqa: F401
     summarizeEstimates, yLogpdf, predict, doTRange, getN, getNX, getNU, getNumPosteriorSamples,
 )
 from . import synth  # noqa: F401
+from .sharded import predict_sharded, shard_range  # noqa: F401
