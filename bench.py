@@ -170,8 +170,15 @@ def main():
         }
         if launches > 0 and kms > 0:
             ach = kflop / (kms * 1e-3) / 1e12
+            # HBM bytes per launch of this kernel from the committed PMC passes of this same command
+            # (separate rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950 correction; tools/profile_r01.sh)
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_tile_gemm.json")
+            if os.path.exists(pmc) and (n, D, K, L, Sr) == (4096, 8, 2, 1, 512) and a.max_batch == 0 and a.panel == 0:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
+                               "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
+                               "traffic_note": "bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_tile_gemm.md",
                                "kernel": "tile_gemm_nt_kernel<1> (f64 MFMA tile update)",
                                "launches": int(launches), "avg_launch_ms": kms / launches,
                                "algorithmic_flop_per_launch": kflop / launches,

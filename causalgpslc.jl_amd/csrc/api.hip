@@ -58,7 +58,7 @@ struct gpslc_ctx {
     bool has_data = false;
     int max_batch = 0;   // 0 = auto
     int panel = 8;
-    int nstreams = 2;
+    int nstreams = 1;   // chunks of one call alternate over this many HIP streams (2 buys ~1-2 %, see profiles/)
     std::vector<hipStream_t> streams;
     std::vector<Arena> arenas;     // one per stream slot
     Arena scratch;                 // call-level buffers (host-pointer entry points, info, ...)
@@ -141,7 +141,19 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
             c->prof.push_back(r);
         }
         ProfRec& r = c->prof[c->prof_used++];
-        r.flop = 2.0 * GP_TS * GP_TS * GP_TS * (double)(g.k1 - g.k0) * (double)g.ntiles * (double)g.nbatch;
+        // algorithmic flop: full tiles count 2*128^3 per K tile, items in the (single) augmented row only
+        // their live right-hand-side rows
+        double short_items = 0;
+        if (g.short_rows > 0) {
+            const int last = g.i0 + g.mi - 1;                       // last output tile row of the launch
+            if (last >= g.short_row0) short_items = (g.shape == 0) ? (double)g.mi : (double)g.mj;
+        }
+        // diagonal tiles of a symmetric (lower-triangle) launch need only their lower triangle: half a
+        // tile product, as in the textbook N^3/3 count (the kernel computes the whole tile)
+        const double diag_items = (g.shape == 0) ? (double)g.mi : 0.0;
+        const double rows = GP_TS * ((double)g.ntiles - short_items - 0.5 * diag_items)
+                          + (double)g.short_rows * short_items;
+        r.flop = 2.0 * GP_TS * GP_TS * rows * (double)(g.k1 - g.k0) * (double)g.nbatch;
         HC(hipEventRecord(r.a, st));
         launch_tile_gemm(g, st);
         HC(hipEventRecord(r.b, st));
@@ -204,7 +216,10 @@ TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstri
 // trailing (ntot-nt)^2 block its Schur complement.  Panels of `pw` tile columns: left-looking inside a
 // panel, one right-looking trailing update (K = pw*128) per panel.
 void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, long long inv_bstride,
-                 int* info, int info_base, int nb, hipStream_t st) {
+                 int* info, int info_base, int nb, hipStream_t st, int aug_rows = 0) {
+    // aug_rows > 0: the tile rows nt.. hold only that many live rows in total (right-hand sides);
+    // a single augmented tile row is the common case and the only one the kernel shortens
+    const int short_rows = (aug_rows > 0 && ntot == nt + 1) ? aug_rows : 0;
     const int pw = std::max(1, c->panel);
     TRef invref = TRef{inv, inv_bstride, 1, 0, 0, 0};   // tile (j, kk) -> inv[kk]
     for (int k = 0; k < nt; ++k) {
@@ -215,6 +230,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             g.A = M; g.B = M; g.C = M;
             g.shape = 1; g.i0 = k; g.j0 = k; g.mi = ntot - k; g.mj = 1;
             g.k0 = ka; g.k1 = k; g.accumulate = 1; g.nbatch = nb; g.ntiles = g.mi;
+            g.short_row0 = nt; g.short_rows = short_rows;
             gemm(c, g, st);
         }
         launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
@@ -223,6 +239,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             g.A = M; g.B = invref; g.C = M;
             g.shape = 1; g.i0 = k + 1; g.j0 = k; g.mi = ntot - k - 1; g.mj = 1;
             g.k0 = k; g.k1 = k + 1; g.accumulate = 0; g.nbatch = nb; g.ntiles = g.mi;
+            g.short_row0 = nt; g.short_rows = short_rows;
             gemm(c, g, st);
         }
         if (k == kend - 1 && ntot - kend > 0) {   // trailing update with the whole panel
@@ -232,6 +249,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             g.shape = 0; g.i0 = kend; g.j0 = kend; g.mi = m; g.mj = m;
             g.k0 = ka; g.k1 = kend; g.accumulate = 1; g.nbatch = nb; g.ntiles = m * (m + 1) / 2;
             g.order = tri_order(c, m);
+            g.short_row0 = nt; g.short_rows = short_rows;
             gemm(c, g, st);
         }
     }
@@ -351,7 +369,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io) {
         ra.part = part; ra.bsum = bsum; ra.ksum = ksum; ra.sumdelta = sumdelta; ra.M = M;
         launch_rhs(ra, nb, st);
 
-        potrf_tiles(c, M, nt, ntot, inv, inv_bs, io.info + s0, 0, nb, st);
+        potrf_tiles(c, M, nt, ntot, inv, inv_bs, io.info + s0, 0, nb, st, (with_sums ? L : 0) + 1);
 
         EpiArgs ea{};
         ea.M = M; ea.n = n; ea.nt = nt; ea.naug = naug; ea.L = with_sums ? L : 0; ea.s0 = s0; ea.S = io.S;

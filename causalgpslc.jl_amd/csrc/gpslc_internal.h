@@ -40,6 +40,8 @@ struct GemmArgs {
     int accumulate;   // 1: C -= A B^T, 0: C = A B^T
     int nbatch;
     int ntiles;       // output tiles per batch element
+    int short_row0;   // output tile rows >= short_row0 (augmented right-hand-side rows) carry only
+    int short_rows;   // `short_rows` live rows: dead 16-row sub-tiles are skipped (0 = feature off)
     const unsigned short* order;  // optional (ii, jj) pairs: output-tile visiting order (L2-blocked), or null
     unsigned long long* dbg;      // diagnostic builds only: per-workgroup s_memtime stamps, or null
 };

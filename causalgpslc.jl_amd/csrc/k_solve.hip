@@ -6,10 +6,9 @@
 #define MAXF 32
 
 // ---------------------------------------------------------------------------------------
-// Back-substitution L^T alpha = z as nt dependent launches (right-looking):
-// launch i: every workgroup (k <= i, b) recomputes alpha_i = inv(L_ii)^T z_i (bit-identical in all
-// of them); workgroup k == i publishes alpha_i, workgroups k < i update z_k -= L(i,k)^T alpha_i.
-// z_i is only read in launch i, so there is no intra-launch hazard.
+// Back-substitution L^T alpha = z, right-looking over tile rows i = nt-1 .. 0, two launches per row:
+// alpha_i = inv(L_ii)^T z_i (one workgroup per matrix), then z_k -= L(i,k)^T alpha_i for every k < i
+// (one workgroup per tile; reads L exactly once: HBM-bound).
 // ---------------------------------------------------------------------------------------
 // (t^T v)_c for the 32 columns c = wave*32 .. +31 of a column-major 128 x 128 tile: every lane loads its
 // two rows of all 32 columns first (64 independent 8-byte loads in flight), then the wave reduces.
@@ -31,29 +30,34 @@ __device__ __forceinline__ void tile_tv32(const double* __restrict__ t, const do
     }
 }
 
-__global__ __launch_bounds__(256) void backsolve_step_kernel(BackArgs a, int i, double* alpha) {
+// alpha_i = inv(L_ii)^T z_i, one workgroup per matrix
+__global__ __launch_bounds__(256) void backsolve_alpha_kernel(BackArgs a, int i, double* alpha) {
     __shared__ double zi[GP_TS];
-    __shared__ double ai[GP_TS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = blockIdx.x;
-    const long long b = blockIdx.y;
+    const long long b = blockIdx.x;
     const int Np = a.nt * GP_TS;
-    double* z = a.zwork + b * Np;
-    if (tid < GP_TS) zi[tid] = z[i * GP_TS + tid];
+    if (tid < GP_TS) zi[tid] = a.zwork[b * Np + i * GP_TS + tid];
     __syncthreads();
     const double* invt = a.inv + b * a.inv_bstride + (long long)i * GP_TSQ;
     double o32[32];
     tile_tv32(invt, zi, wave, lane, o32);
     if (lane == 0) {
 #pragma unroll
-        for (int cc = 0; cc < 32; ++cc) ai[wave * 32 + cc] = o32[cc];
+        for (int cc = 0; cc < 32; ++cc) alpha[b * Np + i * GP_TS + wave * 32 + cc] = o32[cc];
     }
+}
+// z_k -= L(i,k)^T alpha_i for k < i, one workgroup per (k, matrix)
+__global__ __launch_bounds__(256) void backsolve_update_kernel(BackArgs a, int i, const double* alpha) {
+    __shared__ double ai[GP_TS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = blockIdx.x;
+    const long long b = blockIdx.y;
+    const int Np = a.nt * GP_TS;
+    if (tid < GP_TS) ai[tid] = alpha[b * Np + i * GP_TS + tid];
     __syncthreads();
-    if (k == i) {
-        if (tid < GP_TS) alpha[b * Np + i * GP_TS + tid] = ai[tid];
-        return;
-    }
+    double o32[32];
     tile_tv32(tref_tile(a.M, b, i, k), ai, wave, lane, o32);
+    double* z = a.zwork + b * Np;
     if (lane == 0) {
 #pragma unroll
         for (int cc = 0; cc < 32; ++cc) z[k * GP_TS + wave * 32 + cc] -= o32[cc];
@@ -72,8 +76,10 @@ void launch_backsolve(const BackArgs& a, int nbatch, hipStream_t st) {
     // alpha is stored right behind zwork (caller allocates 2 * nbatch * Np doubles)
     double* alpha = a.zwork + (long long)nbatch * a.nt * GP_TS;
     hipLaunchKernelGGL(extract_z_kernel, dim3(a.nt, nbatch), dim3(128), 0, st, a);
-    for (int i = a.nt - 1; i >= 0; --i)
-        hipLaunchKernelGGL(backsolve_step_kernel, dim3(i + 1, nbatch), dim3(256), 0, st, a, i, alpha);
+    for (int i = a.nt - 1; i >= 0; --i) {
+        hipLaunchKernelGGL(backsolve_alpha_kernel, dim3(nbatch), dim3(256), 0, st, a, i, alpha);
+        if (i > 0) hipLaunchKernelGGL(backsolve_update_kernel, dim3(i, nbatch), dim3(256), 0, st, a, i, alpha);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -90,6 +90,13 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         const int ti = g.i0 + ii, tj = g.j0 + jj;
 
         double* __restrict__ Ct = tref_tile(g.C, b, ti, tj);
+        // augmented right-hand-side rows hold only `short_rows` live rows: this wave's number of live
+        // 16-row sub-tiles (wave-uniform); the dead ones keep their (zero) C values untouched
+        int mlive = 4;
+        if (g.short_rows > 0 && ti >= g.short_row0) {
+            const int mt = (g.short_rows + 15) >> 4;
+            mlive = min(4, max(0, mt - 4 * wr));
+        }
         unsigned long long st0 = 0, st1 = 0, st2 = 0;
         if (g.dbg) st0 = __builtin_amdgcn_s_memtime();
 
@@ -133,9 +140,13 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                     *reinterpret_cast<d2*>(lB + buf * OPER_LDS + loff[u]) = xb[u];
                 }
             };
-            auto compute = [&](int buf) {
+            auto compute = [&](int buf, int s) {
                 const double* pa = lA + buf * OPER_LDS + frow_a;
                 const double* pb = lB + buf * OPER_LDS + frow_b;
+                // Panel product (ACC == 0): B is the lower-triangular inverse inv(L_kk)[c][c'], zero for
+                // c' > c.  Slab s carries c' in [16 (s&7), 16 (s&7) + 16), so only the output column
+                // sub-tiles n with 64 wc + 16 n + 15 >= 16 (s&7) contribute: 44 % fewer MFMAs.
+                const int nlo = ACC ? 0 : min(4, max(0, (s & 7) - 4 * wc));
 #pragma unroll
                 for (int ks = 0; ks < KS / 4; ++ks) {
                     double af[4], bf[4];
@@ -143,11 +154,21 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                     for (int m = 0; m < 4; ++m) af[m] = pa[ks * 4 * LROW + 16 * m];
 #pragma unroll
                     for (int n = 0; n < 4; ++n) bf[n] = pb[ks * 4 * LROW + 16 * n];
+                    if (mlive == 4 && nlo == 0) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
+                        for (int m = 0; m < 4; ++m)
 #pragma unroll
-                        for (int n = 0; n < 4; ++n)
-                            acc[m][n] = mfma_step<ACC>(bf[n], af[m], acc[m][n]);
+                            for (int n = 0; n < 4; ++n)
+                                acc[m][n] = mfma_step<ACC>(bf[n], af[m], acc[m][n]);
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            if (m < mlive) {
+#pragma unroll
+                                for (int n = 0; n < 4; ++n)
+                                    if (n >= nlo) acc[m][n] = mfma_step<ACC>(bf[n], af[m], acc[m][n]);
+                            }
+                    }
                 }
             };
 
@@ -161,11 +182,11 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
             // against the next work item's first lstore.
             for (int s = 0; s < nslab; s += 2) {
                 if (s + 2 < nslab) gload(s + 2, ra2, rb2);
-                compute(0);
+                compute(0, s);
                 lstore(1, ra, rb);
                 __syncthreads();
                 if (s + 3 < nslab) gload(s + 3, ra, rb);
-                compute(1);
+                compute(1, s + 1);
                 if (s + 2 < nslab) lstore(0, ra2, rb2);
                 __syncthreads();
             }

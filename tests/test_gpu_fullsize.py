@@ -1,0 +1,120 @@
+"""BASELINE.json's full-size configurations on the GPU.
+
+The literal oracle costs ~13 N^3 flop per unit, so at these sizes parity is checked (a) against the
+oracle's structured form (one NumPy Cholesky, seconds) for a few posterior samples and (b) through
+size-independent properties for all of them:
+  * mean_i MeanITE_i == MeanSATE — two independent code paths (back-substitution + N^2 pass vs the
+    Schur complement of the augmented factorisation);
+  * exact zeros when every T equals doT (test/estimation.jl:6-136 at scale);
+  * invariance of the SATE under a permutation of the instances;
+  * independence of batch / stream / panel tuning.
+"""
+import numpy as np
+import pytest
+
+import gpslc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _obj(gp, n, D, K, S, binary=False, seed=1234):
+    X, T, Y, objid = gp.synth.make_dataset(n, D, binary_t=binary, seed=seed)
+    post = gp.synth.make_posterior(n, D, K, S, objid, seed=seed)
+    g = gp.GPSLCObject(X, T, Y, post["U"], post["uyLS"], post["xyLS"], post["tyLS"], post["yNoise"], post["yScale"])
+    return g, (X, T, Y, post)
+
+
+def _sample(post, s, D, K):
+    return orc.PosteriorSample(post["uyLS"][:, s] if K else None, post["xyLS"][:, s] if D else None,
+                               float(post["tyLS"][s]), float(post["yNoise"][s]), float(post["yScale"][s]),
+                               post["U"][:, :, s] if K else None)
+
+
+def _check_vs_structured(ms, vs, mi, lp, data, doTs, which, D, K):
+    X, T, Y, post = data
+    n = len(Y)
+    for s in which:
+        p = _sample(post, s, D, K)
+        rm, rv, logdet, quad = orc.structured_sate(p, X, T, Y, doTs)
+        for l in range(len(doTs)):
+            assert abs(ms[s, l] - rm[l]) <= 1e-6 * abs(rm[l]) + 1e-12          # north-star tolerance
+            assert abs(vs[s, l] - rv[l]) <= 1e-6 * abs(rv[l]) + 1e-9 * p.yScale
+            assert abs(ms[s, l] - rm[l]) <= 1e-9 * abs(rm[l]) + 1e-13          # what fp64 delivers
+        ref_lp = -0.5 * (n * np.log(2 * np.pi) + logdet + quad)
+        assert abs(lp[s] - ref_lp) <= 1e-10 * abs(ref_lp)
+        if mi is not None and n <= 2048:
+            m, _ = orc.structured_ite(p, X, T, Y, doTs[0])
+            assert np.max(np.abs(mi[:, s, 0] - m)) <= 1e-8 * np.max(np.abs(m)) + 1e-13
+
+
+def test_config2_n1024_d4_nu1(gp):
+    """BASELINE configs[1]: Synthetic N=1024 D=4 nU=1 continuous treatment."""
+    n, D, K, S = 1024, 4, 1, 48
+    g, data = _obj(gp, n, D, K, S)
+    doTs = gp.synth.levels(data[1], 3)
+    ms, vs, mi = gp.predict(g, doTs, want_mean_ite=True)
+    lp = gp.yLogpdf(g)
+    _check_vs_structured(ms, vs, mi, lp, data, doTs, [0, 17, 47], D, K)
+    assert np.max(np.abs(mi.mean(axis=0) - ms)) <= 1e-10 * np.max(np.abs(ms)) + 1e-13
+    # one unit against the LITERAL restatement (5 kernels, 3 Bunch-Kaufman solves, 4 GEMMs)
+    p = _sample(data[3], 5, D, K)
+    M, Cv = orc.ite_distributions([p], data[0], data[1], data[2], doTs[1])
+    rm, rv = orc.conditional_sate(M[0], Cv[0])
+    assert abs(ms[5, 1] - rm) <= 1e-6 * abs(rm) + 1e-12
+    assert abs(vs[5, 1] - rv) <= 1e-6 * abs(rv) + 1e-9 * p.yScale
+    assert np.max(np.abs(mi[:, 5, 1] - M[0])) <= 1e-6 * np.max(np.abs(M[0])) + 1e-12
+
+
+def test_config3_n4096_d8_nu2(gp):
+    """BASELINE configs[2]: Synthetic N=4096 D=8 nU=2 (the bench workload)."""
+    n, D, K, S = 4096, 8, 2, 24
+    g, data = _obj(gp, n, D, K, S)
+    doTs = gp.synth.levels(data[1], 2)
+    ms, vs, mi = gp.predict(g, doTs, want_mean_ite=True)
+    lp = gp.yLogpdf(g)
+    assert np.all(np.isfinite(ms)) and np.all(np.isfinite(vs)) and np.all(vs > 0)
+    _check_vs_structured(ms, vs, None, lp, data, doTs, [3], D, K)
+    assert np.max(np.abs(mi.mean(axis=0) - ms)) <= 1e-10 * np.max(np.abs(ms)) + 1e-13
+    # tuning independence at full size
+    g2, _ = _obj(gp, n, D, K, S)
+    g2.ctx().set_tuning(5, 3, 3)
+    ms2, vs2, _ = gp.predict(g2, doTs)
+    assert np.allclose(ms2, ms, rtol=1e-11, atol=1e-14) and np.allclose(vs2, vs, rtol=1e-9, atol=1e-14)
+
+
+def test_permutation_invariance_n1024(gp):
+    n, D, K, S = 1024, 4, 1, 6
+    g, (X, T, Y, post) = _obj(gp, n, D, K, S, seed=77)
+    doTs = gp.synth.levels(T, 2)
+    ms, vs, _ = gp.predict(g, doTs)
+    perm = np.random.default_rng(0).permutation(n)
+    gperm = gp.GPSLCObject(X[perm], T[perm], Y[perm], post["U"][perm], post["uyLS"], post["xyLS"], post["tyLS"],
+                           post["yNoise"], post["yScale"])
+    ms2, vs2, _ = gp.predict(gperm, doTs)
+    assert np.allclose(ms2, ms, rtol=1e-10, atol=1e-13)
+    assert np.allclose(vs2, vs, rtol=1e-8, atol=1e-13)
+
+
+def test_exact_zero_identity_at_n2048(gp):
+    """doT == T for every instance: MeanITE, MeanSATE exactly 0, VarSATE exactly eps / n."""
+    n, D, K, S = 2048, 8, 2, 4
+    X, _, Y, objid = gp.synth.make_dataset(n, D)
+    T = np.full(n, 0.75)
+    post = gp.synth.make_posterior(n, D, K, S, objid)
+    g = gp.GPSLCObject(X, T, Y, post["U"], post["uyLS"], post["xyLS"], post["tyLS"], post["yNoise"], post["yScale"])
+    ms, vs, mi = gp.predict(g, [0.75], want_mean_ite=True)
+    assert np.all(ms == 0.0) and np.all(mi == 0.0)
+    assert np.array_equal(vs, np.full_like(vs, (n * 1e-10) / (float(n) * float(n))))
+
+
+def test_config5_n16384_d16_nu4_binary(gp):
+    """BASELINE configs[4] shape on one GPU (fp64 throughout): N=16384 D=16 nU=4 binary treatment."""
+    n, D, K, S = 16384, 16, 4, 2
+    g, data = _obj(gp, n, D, K, S, binary=True)
+    doTs = np.array([0.0, 1.0])
+    ms, vs, mi = gp.predict(g, doTs, want_mean_ite=True)
+    assert np.all(np.isfinite(ms)) and np.all(vs > 0)
+    assert np.max(np.abs(mi.mean(axis=0) - ms)) <= 1e-10 * np.max(np.abs(ms)) + 1e-13
+    # binary T: an instance already at the intervention level has r_j == e_ij for its own row only; the
+    # ITE of "doT = its own treatment" is not zero in general, but MeanSATE(0) and MeanSATE(1) differ
+    assert np.all(np.abs(ms[:, 0] - ms[:, 1]) > 0)
