@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-units", type=int, default=2)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--fp32-kernel", action="store_true", help="mixed precision: RBF evaluation in fp32 (config 5)")
     return ap.parse_args()
 
 
@@ -84,9 +85,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # functional rehearsal of the N > 1 path on a one-GPU box: every rank uses device 0 and the process
+    # group is gloo (RCCL refuses two ranks on one device); never used for reported numbers
+    rehearsal = os.environ.get("GPSLC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -112,7 +121,7 @@ def main():
     def ptr(t):
         return None if t is None else C.c_void_p(t.data_ptr())
 
-    ctx = gp.Context(n, D, K, device=local_rank, profile=not a.no_profile)
+    ctx = gp.Context(n, D, K, device=local_rank, profile=not a.no_profile, fp32_kernel=a.fp32_kernel)
     ctx.check(ctx.lib.gpslc_set_data_dev(ctx.h, ptr(dX), ptr(dT), ptr(dY)))
     ctx.set_tuning(a.max_batch, a.panel, a.streams)
 
@@ -124,8 +133,13 @@ def main():
                                        ptr(ddo), 1e-10, 0, 0, None, ptr(mS), ptr(vS), ptr(mI), None)
         ctx.check(st)
         if world > 1:   # the single end-of-step collective: SATE summaries of every rank's shard
-            dist.all_gather(gathered_m, mS)
-            dist.all_gather(gathered_v, vS)
+            if rehearsal:   # gloo: gather through host memory
+                gm = [torch.empty(Sr * L, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(gm, mS.cpu())
+                dist.all_gather(gm, vS.cpu())
+            else:
+                dist.all_gather(gathered_m, mS)
+                dist.all_gather(gathered_v, vS)
 
     def fence():
         torch.cuda.synchronize()
@@ -143,7 +157,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     launches, kms, kflop = ctx.profile_get()
@@ -157,12 +171,12 @@ def main():
         if mI is not None:
             mi_h = mI.cpu().numpy().reshape(n, Sr, L, order="F")
             chk = np.max(np.abs(mi_h.mean(axis=0)[:, 0] - ms_h.reshape(Sr, L, order="F")[:, 0]))
-            assert chk <= 1e-8 * max(1.0, np.max(np.abs(ms_h))), chk
+            assert chk <= (1e-5 if a.fp32_kernel else 1e-8) * max(1.0, np.max(np.abs(ms_h))), chk
         out = {
             "metric": "posterior samples/sec (kernel+chol+predict) at N=%d" % n,
             "value": val, "unit": "posterior samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64" if not a.fp32_kernel else "f64 factorisation, f32 kernel build", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo — not a result)" if rehearsal else ""),
             "config": {"workload": f"Synthetic N={n} D={D} nU={K}, unit A (Gram build + potrf + alpha + MeanITE + "
                                    f"SATE mean/var), L={L} level(s), {Sr} posterior samples per GPU per step",
                        "samples_per_gpu_per_step": Sr, "levels": L, "mean_ite": not a.no_mean_ite,

@@ -46,11 +46,12 @@ def _p(a):
 class Context:
     """RAII wrapper of gpslc_ctx (one per GPU and data set)."""
 
-    def __init__(self, n, nX, nU, device=0, profile=False):
+    def __init__(self, n, nX, nU, device=0, profile=False, fp32_kernel=False):
         self.lib = _lib.load()
         self.n, self.nX, self.nU = int(n), int(nX), int(nU)
         h = C.c_void_p()
-        st = self.lib.gpslc_create(C.byref(h), int(device), self.n, self.nX, self.nU, 1 if profile else 0)
+        st = self.lib.gpslc_create(C.byref(h), int(device), self.n, self.nX, self.nU,
+                                   (1 if profile else 0) | (2 if fp32_kernel else 0))
         if st != 0:
             raise GPSLCError(st, {-1003: "no usable gfx950 device"}.get(st, "gpslc_create failed"))
         self.h = h
@@ -182,6 +183,7 @@ class GPSLCObject:
     yScale: np.ndarray
     hyperparams: HyperParameters = field(default_factory=HyperParameters)
     device: int = 0
+    fp32_kernel: bool = False   # GPSLC_FLAG_FP32_KERNEL: RBF evaluation in fp32, factorisation in fp64
     _ctx: Optional[Context] = field(default=None, repr=False)
 
     def __post_init__(self):
@@ -222,7 +224,7 @@ class GPSLCObject:
 
     def ctx(self) -> Context:
         if self._ctx is None:
-            c = Context(self.getN(), self.getNX(), self.getNU(), device=self.device)
+            c = Context(self.getN(), self.getNX(), self.getNU(), device=self.device, fp32_kernel=self.fp32_kernel)
             c.set_data(self.X, self.T, self.Y)
             self._ctx = c
         return self._ctx

@@ -361,6 +361,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io) {
         ga.X = io.X; ga.T = c->dT; ga.p = io.p; ga.s0 = s0;
         ga.n = n; ga.nX = c->nX; ga.nU = c->nU; ga.nt = nt; ga.M = M; ga.part = part;
         ga.with_sums = with_sums ? 1 : 0;
+        ga.f32 = (c->flags & GPSLC_FLAG_FP32_KERNEL) ? 1 : 0;
         launch_gram(ga, nb, st);
 
         RhsArgs ra{};
@@ -385,6 +386,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io) {
             IteMeanArgs ia{};
             ia.X = io.X; ia.T = c->dT; ia.p = io.p; ia.s0 = s0; ia.S = io.S;
             ia.n = n; ia.nX = c->nX; ia.nU = c->nU; ia.nt = nt; ia.L = L; ia.doT = io.doT; ia.alpha = alpha;
+            ia.f32 = (c->flags & GPSLC_FLAG_FP32_KERNEL) ? 1 : 0;
             if (meanITE) {
                 ia.meanITE = meanITE; ia.si = 1; ia.ss = n; ia.sl = (long long)n * io.S;
                 launch_ite_mean(ia, nb, st);

@@ -28,3 +28,12 @@ __device__ __forceinline__ double gp_exp_neg(double x) {
     p = fma(p, r, 1.0);
     return ldexp(p, (int)k);
 }
+
+// The two arithmetic flavours of the fused RBF evaluation: fp64 (default) and fp32 (mixed-precision mode).
+template <typename RT> struct RbfMath;
+template <> struct RbfMath<double> {
+    static __device__ __forceinline__ double exp_neg(double x) { return gp_exp_neg(x); }
+};
+template <> struct RbfMath<float> {
+    static __device__ __forceinline__ float exp_neg(float x) { return expf(x); }   // exact 1 at +-0
+};

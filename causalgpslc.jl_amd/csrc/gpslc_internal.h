@@ -65,6 +65,7 @@ struct GramArgs {
     TRef M;            // lower-packed tile matrix of the chunk
     double* part;      // [b][2][nt][Np] partial column sums of B (0) and K (1)
     int with_sums;
+    int f32;           // evaluate the RBF kernel in fp32 (GPSLC_FLAG_FP32_KERNEL)
 };
 
 // launchers (implemented in the k_*.hip files); all asynchronous on `st`
@@ -101,6 +102,7 @@ struct IteMeanArgs {
     const double* alpha;   // [b][Np]
     double* meanITE;       // element (i, s, l) at i*si + s*ss + l*sl
     long long si, ss, sl;
+    int f32;
 };
 void launch_ite_mean(const IteMeanArgs& a, int nbatch, hipStream_t st);
 

@@ -26,14 +26,15 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /* >= 4 do
 // Gram build: one workgroup per lower tile (ti >= tj) per posterior sample.
 // Thread (tx = tid>>4, ty = tid&15) owns rows ty + 16p and columns 8 tx + q, p, q = 0..7.
 // ---------------------------------------------------------------------------------------
+template <typename RT>
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = g.nU + g.nX;
-    double* fr = sm;                     // [F][128] row-block features, pre-scaled by 1/LS
-    double* fc = fr + F * GP_TS;         // [F][128] column-block features, pre-scaled by 1/LS
-    double* tr = fc + F * GP_TS;         // [128] T of row block
-    double* tc = tr + GP_TS;             // [128]
-    double* red = tc + GP_TS;            // [4][128][2] cross-wave row-sum staging
+    double* red = sm;                    // [4][128][2] cross-wave row-sum staging
+    RT* fr = reinterpret_cast<RT*>(red + 4 * GP_TS * 2);   // [F][128] row-block features / LS
+    RT* fc = fr + F * GP_TS;             // [F][128] column-block features / LS
+    RT* tr = fc + F * GP_TS;             // [128] T of row block
+    RT* tc = tr + GP_TS;                 // [128]
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -57,22 +58,22 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
         if (f < g.nU) { src = g.p.U + (s * g.nU + f) * (long long)n; l = g.p.uyLS[s * g.nU + f]; }
         else { src = g.X + (long long)(f - g.nU) * n; l = g.p.xyLS[s * g.nX + (f - g.nU)]; }
         const double il = 1.0 / l;
-        fr[f * GP_TS + r] = (gi0 + r < n) ? src[gi0 + r] * il : 0.0;
-        fc[f * GP_TS + r] = (gj0 + r < n) ? src[gj0 + r] * il : 0.0;
+        fr[f * GP_TS + r] = (RT)((gi0 + r < n) ? src[gi0 + r] * il : 0.0);
+        fc[f * GP_TS + r] = (RT)((gj0 + r < n) ? src[gj0 + r] * il : 0.0);
     }
     if (tid < GP_TS) {
-        tr[tid] = (gi0 + tid < n) ? g.T[gi0 + tid] : 0.0;
-        tc[tid] = (gj0 + tid < n) ? g.T[gj0 + tid] : 0.0;
+        tr[tid] = (RT)((gi0 + tid < n) ? g.T[gi0 + tid] : 0.0);
+        tc[tid] = (RT)((gj0 + tid < n) ? g.T[gj0 + tid] : 0.0);
     }
     __syncthreads();
 
     const double ys = g.p.yScale[s];
     const double yn = g.p.yNoise[s];
     const double tl = g.p.tyLS[s];
-    const double wt = 1.0 / (tl * tl);
+    const RT wt = (RT)(1.0 / (tl * tl));
     const int ty = tid & 15, tx = tid >> 4;
 
-    double tra[8];
+    RT tra[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) tra[p] = tr[ty + 16 * p];
 
@@ -90,27 +91,28 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     for (int q = 0; q < 8; ++q) {
         const int cq = 8 * tx + q;
         const int gj = gj0 + cq;
-        double lux[8];
+        RT lux[8];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) lux[p] = 0.0;
+        for (int p = 0; p < 8; ++p) lux[p] = (RT)0;
         for (int f = 0; f < F; ++f) {
-            const double c = fc[f * GP_TS + cq];
+            const RT c = fc[f * GP_TS + cq];
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                const double d = fr[f * GP_TS + ty + 16 * p] - c;
+                const RT d = fr[f * GP_TS + ty + 16 * p] - c;
                 lux[p] = fma(d, d, lux[p]);
             }
         }
-        const double tcq = tc[cq];
+        const RT tcq = tc[cq];
         double csB = 0.0, csK = 0.0;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int rp = ty + 16 * p;
             const int gi = gi0 + rp;
-            const double dt = tra[p] - tcq;
-            double Bv = ys * gp_exp_neg(-lux[p]);
-            double Ev = gp_exp_neg(-((dt * dt) * wt));
-            double Kv = Bv * Ev;
+            const RT dt = tra[p] - tcq;
+            const RT Bq = (RT)ys * RbfMath<RT>::exp_neg(-lux[p]);
+            const RT Eq = RbfMath<RT>::exp_neg(-((dt * dt) * wt));
+            double Bv = (double)Bq;
+            double Kv = (double)(Bq * Eq);
             double Av = Kv;
             const bool inside = (gi < n) && (gj < n);
             if (!inside) { Bv = 0.0; Kv = 0.0; Av = (gi == gj) ? 1.0 : 0.0; }
@@ -156,18 +158,24 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     }
 }
 
-#define GRAM_LDS_BYTES(F) ((2 * (F) * GP_TS + 2 * GP_TS + 4 * GP_TS * 2) * 8)
+#define GRAM_LDS_BYTES(F, RTS) (4 * GP_TS * 2 * 8 + (2 * (F) * GP_TS + 2 * GP_TS) * (RTS))
 
 void launch_gram(const GramArgs& g, int nbatch, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GRAM_LDS_BYTES(MAXF));
+        (void)hipFuncSetAttribute((const void*)gram_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GRAM_LDS_BYTES(MAXF, 8));
+        (void)hipFuncSetAttribute((const void*)gram_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GRAM_LDS_BYTES(MAXF, 4));
         attr_set = true;
     }
     // one workgroup per (tile, sample): a persistent variant measured 0.7 % slower (same-box A/B)
     const int nlow = g.nt * (g.nt + 1) / 2;
-    hipLaunchKernelGGL(gram_kernel, dim3(nlow, nbatch), dim3(256), GRAM_LDS_BYTES(g.nU + g.nX), st, g);
+    const int F = g.nU + g.nX;
+    if (g.f32)
+        hipLaunchKernelGGL(gram_kernel<float>, dim3(nlow, nbatch), dim3(256), GRAM_LDS_BYTES(F, 4), st, g);
+    else
+        hipLaunchKernelGGL(gram_kernel<double>, dim3(nlow, nbatch), dim3(256), GRAM_LDS_BYTES(F, 8), st, g);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -87,15 +87,15 @@ void launch_backsolve(const BackArgs& a, int nbatch, hipStream_t st) {
 // D = Ks' - K formed element-wise so that doT == T gives exact zeros, test/estimation.jl:6-66).
 // One workgroup per (row block, sample); levels are processed LC at a time.
 // ---------------------------------------------------------------------------------------
-template <int FREG, int LCT>
+template <int FREG, int LCT, typename RT>
 __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = a.nU + a.nX;
-    double* fc = sm;                       // [FREG][128] column-block features / LS (zero rows beyond F)
-    double* tcs = fc + FREG * GP_TS;       // [128]
-    double* al = tcs + GP_TS;              // [128]
+    double* al = sm;                       // [128]
     double* rl = al + GP_TS;               // [LCT][128]
     double* red = rl + LCT * GP_TS;        // [128][LCT]
+    RT* fc = reinterpret_cast<RT*>(red + GP_TS * LCT);   // [FREG][128] column features / LS (zero rows beyond F)
+    RT* tcs = fc + FREG * GP_TS;           // [128]
     const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;
     const int ib = blockIdx.x;
     const long long b = blockIdx.y, s = a.s0 + b;
@@ -108,13 +108,14 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     auto feat_il = [&](int f) -> double {
         return 1.0 / ((f < a.nU) ? a.p.uyLS[s * a.nU + f] : a.p.xyLS[s * a.nX + (f - a.nU)]);
     };
-    double af[FREG];   // this thread's row features / LS
+    RT af[FREG];   // this thread's row features / LS
 #pragma unroll
-    for (int f = 0; f < FREG; ++f) af[f] = (f < F && gi < n) ? feat_src(f)[gi] * feat_il(f) : 0.0;
+    for (int f = 0; f < FREG; ++f) af[f] = (RT)((f < F && gi < n) ? feat_src(f)[gi] * feat_il(f) : 0.0);
     const double ys = a.p.yScale[s];
     const double tl = a.p.tyLS[s];
     const double wt = 1.0 / (tl * tl);
-    const double tri = (gi < n) ? a.T[gi] : 0.0;
+    const RT wtq = (RT)wt;
+    const RT tri = (RT)((gi < n) ? a.T[gi] : 0.0);
     const double* alpha = a.alpha + b * Np;
 
     for (int l0 = 0; l0 < a.L; l0 += LCT) {
@@ -127,11 +128,11 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
             for (int idx = tid; idx < FREG * GP_TS; idx += 256) {
                 const int f = idx >> 7, cc = idx & 127;
                 const int g = jt * GP_TS + cc;
-                fc[idx] = (f < F && g < n) ? feat_src(f)[g] * feat_il(f) : 0.0;
+                fc[idx] = (RT)((f < F && g < n) ? feat_src(f)[g] * feat_il(f) : 0.0);
             }
             if (tid < GP_TS) {
                 const int g = jt * GP_TS + tid;
-                tcs[tid] = (g < n) ? a.T[g] : 0.0;
+                tcs[tid] = (RT)((g < n) ? a.T[g] : 0.0);
                 al[tid] = (g < n) ? alpha[g] : 0.0;
             }
             for (int idx = tid; idx < LCT * GP_TS; idx += 256) {
@@ -139,8 +140,8 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
                 const int g = jt * GP_TS + cc;
                 double v = 0.0;
                 if (ll < nl && g < n) {
-                    const double dt = a.T[g] - a.doT[l0 + ll];
-                    v = gp_exp_neg(-((dt * dt) * wt));
+                    const RT dt = (RT)a.T[g] - (RT)a.doT[l0 + ll];
+                    v = (double)RbfMath<RT>::exp_neg(-((dt * dt) * wtq));
                 }
                 rl[idx] = v;
             }
@@ -148,15 +149,15 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
 #pragma unroll 2
             for (int cq = 0; cq < 64; ++cq) {
                 const int c = h * 64 + cq;
-                double lux = 0.0;
+                RT lux = (RT)0;
 #pragma unroll
                 for (int f = 0; f < FREG; ++f) {
-                    const double d = af[f] - fc[f * GP_TS + c];
+                    const RT d = af[f] - fc[f * GP_TS + c];
                     lux = fma(d, d, lux);
                 }
-                const double dt = tri - tcs[c];
-                const double Bv = ys * gp_exp_neg(-lux);
-                const double Ev = gp_exp_neg(-((dt * dt) * wt));
+                const RT dt = tri - tcs[c];
+                const double Bv = (double)((RT)ys * RbfMath<RT>::exp_neg(-lux));
+                const double Ev = (double)RbfMath<RT>::exp_neg(-((dt * dt) * wtq));
                 const double ba = Bv * al[c];
 #pragma unroll
                 for (int ll = 0; ll < LCT; ++ll) acc[ll] = fma(ba, rl[ll * GP_TS + c] - Ev, acc[ll]);
@@ -178,29 +179,34 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     }
 }
 
-template <int FREG, int LCT>
+template <int FREG, int LCT, typename RT>
 static void launch_ite_mean_t(const IteMeanArgs& a, int nbatch, hipStream_t st) {
-    const int bytes = (FREG * GP_TS + 2 * GP_TS + 2 * LCT * GP_TS) * 8;
+    const int bytes = (GP_TS + 2 * LCT * GP_TS) * 8 + (FREG * GP_TS + GP_TS) * (int)sizeof(RT);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ite_mean_kernel<FREG, LCT>,
+        (void)hipFuncSetAttribute((const void*)ite_mean_kernel<FREG, LCT, RT>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((ite_mean_kernel<FREG, LCT>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
+    hipLaunchKernelGGL((ite_mean_kernel<FREG, LCT, RT>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
 }
-template <int FREG>
+template <int FREG, typename RT>
 static void launch_ite_mean_f(const IteMeanArgs& a, int nbatch, hipStream_t st) {
-    if (a.L <= 1) launch_ite_mean_t<FREG, 1>(a, nbatch, st);
-    else if (a.L <= 4) launch_ite_mean_t<FREG, 4>(a, nbatch, st);
-    else launch_ite_mean_t<FREG, 16>(a, nbatch, st);
+    if (a.L <= 1) launch_ite_mean_t<FREG, 1, RT>(a, nbatch, st);
+    else if (a.L <= 4) launch_ite_mean_t<FREG, 4, RT>(a, nbatch, st);
+    else launch_ite_mean_t<FREG, 16, RT>(a, nbatch, st);
+}
+template <typename RT>
+static void launch_ite_mean_r(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+    const int F = a.nU + a.nX;
+    if (F <= 4) launch_ite_mean_f<4, RT>(a, nbatch, st);
+    else if (F <= 12) launch_ite_mean_f<12, RT>(a, nbatch, st);
+    else if (F <= 20) launch_ite_mean_f<20, RT>(a, nbatch, st);
+    else launch_ite_mean_f<32, RT>(a, nbatch, st);
 }
 void launch_ite_mean(const IteMeanArgs& a, int nbatch, hipStream_t st) {
-    const int F = a.nU + a.nX;
-    if (F <= 4) launch_ite_mean_f<4>(a, nbatch, st);
-    else if (F <= 12) launch_ite_mean_f<12>(a, nbatch, st);
-    else if (F <= 20) launch_ite_mean_f<20>(a, nbatch, st);
-    else launch_ite_mean_f<32>(a, nbatch, st);
+    if (a.f32) launch_ite_mean_r<float>(a, nbatch, st);
+    else launch_ite_mean_r<double>(a, nbatch, st);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -42,6 +42,8 @@ typedef struct gpslc_ctx gpslc_ctx;
 /* flags for gpslc_create */
 #define GPSLC_FLAG_DEFAULT            0u
 #define GPSLC_FLAG_PROFILE            1u   /* record HIP events around the dominant kernels */
+#define GPSLC_FLAG_FP32_KERNEL        2u   /* mixed precision (BASELINE config 5): RBF distances and exp in
+                                              fp32, Gram matrix / Cholesky / solves in fp64                  */
 
 /* ---- context ------------------------------------------------------------------------- */
 

@@ -210,3 +210,26 @@ def test_not_positive_definite_maps_to_posdef_exception(gp):
     assert 1 <= ei.value.info <= n
     info = g.ctx().last_info(1)
     assert info[0] == ei.value.info
+
+
+def test_fp32_kernel_mode_drift_and_identities(gp):
+    """GPSLC_FLAG_FP32_KERNEL (BASELINE config 5): RBF evaluation in fp32, factorisation in fp64.
+    The drift of the SATE against the fp64 path is bounded by fp32 rounding of the Gram entries times the
+    conditioning of A (measured ~1e-6..1e-5 here); the exact-zero identities survive (expf(-0) == 1)."""
+    c = cases.make_case(300, "UX", False, S=4, seed=21)
+    exp = cases.oracle_expected(c)
+    obj32 = cases.gpslc_object(gp, c, fp32_kernel=True)
+    ms, vs, mi = gp.predict(obj32, c["doTs"], want_mean_ite=True)
+    rel_m = np.max(np.abs(ms - exp["meanSATE"]) / np.abs(exp["meanSATE"]))
+    rel_i = np.max(np.abs(mi - exp["meanITE"])) / np.max(np.abs(exp["meanITE"]))
+    assert 1e-12 < rel_m < 1e-3, rel_m          # it IS a different arithmetic, and it stays close
+    assert rel_i < 1e-3
+    assert np.all(np.abs(vs - exp["varSATE"]) <= 1e-2 * np.abs(exp["varSATE"]) + 1e-6 * c["yScale"][:, None])
+    # exact zeros when doT == T everywhere
+    n = 130
+    T = np.full(n, 0.25)
+    rng = np.random.default_rng(0)
+    g = gp.GPSLCObject(rng.standard_normal((n, 2)), T, rng.standard_normal(n), rng.standard_normal((n, 1, 1)),
+                       [[1.3]], [[0.9], [1.7]], [0.8], [0.6], [1.1], fp32_kernel=True)
+    ms, vs, mi = gp.predict(g, [0.25], want_mean_ite=True)
+    assert np.all(ms == 0.0) and np.all(mi == 0.0)
