@@ -319,8 +319,8 @@ void run_predict(gpslc_ctx* c, const PredictIO& io) {
                + 1024;
     int Bb_target = 0;
     if (unitB) {
-        // keep the unit-B sub-batch modest: it multiplies memory by ~3x per unit
-        Bb_target = (int)std::max<long long>(1, std::min<long long>(64, 16384LL / ((long long)nt * nt)));
+        // unit-B sub-batch: 64 units at N = 4096 (203 MB each); larger buys nothing (measured)
+        Bb_target = (int)std::max<long long>(1, std::min<long long>(128, 65536LL / ((long long)nt * nt)));
     }
     const size_t fixed = (size_t)Bb_target * unitB_per + (1 << 20);
     const int Bt = auto_batch(c, io.S, per, fixed);
