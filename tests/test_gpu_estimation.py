@@ -233,3 +233,57 @@ def test_fp32_kernel_mode_drift_and_identities(gp):
                        [[1.3]], [[0.9], [1.7]], [0.8], [0.6], [1.1], fp32_kernel=True)
     ms, vs, mi = gp.predict(g, [0.25], want_mean_ite=True)
     assert np.all(ms == 0.0) and np.all(mi == 0.0)
+
+
+def test_many_levels_two_augmented_tile_rows(gp):
+    """L + 1 > 128 right-hand sides -> two augmented tile rows; the reference's default sweep has 101."""
+    c = cases.make_case(140, "UX", False, S=2, seed=31)
+    doTs = np.linspace(float(c["T"].min()), float(c["T"].max()), 150)
+    obj = cases.gpslc_object(gp, c)
+    ms, vs, mi = gp.predict(obj, doTs, want_mean_ite=True)
+    smp = cases.samples_of(c)
+    for s, p in enumerate(smp):
+        rm, rv, _, _ = orc.structured_sate(p, c["X"], c["T"], c["Y"], doTs)
+        assert np.max(np.abs(ms[s] - rm) / np.abs(rm)) < 1e-8
+        assert np.all(np.abs(vs[s] - rv) <= 1e-8 * np.abs(rv) + 1e-12 * p.yScale)
+    for l in (0, 77, 149):
+        m, _ = orc.structured_ite(smp[1], c["X"], c["T"], c["Y"], doTs[l])
+        assert np.max(np.abs(mi[:, 1, l] - m)) <= 1e-9 * np.max(np.abs(m)) + 1e-13
+
+
+def test_many_samples_tiny_n(gp):
+    """S >> batch with N < 128 (one padded tile): chunking over the sample index."""
+    c = cases.make_case(7, "U", True, S=700, nU=1, seed=8)
+    obj = cases.gpslc_object(gp, c)
+    obj.ctx().set_tuning(64, 0, 2)
+    ms, vs, _ = gp.predict(obj, c["doTs"])
+    smp = cases.samples_of(c)
+    for s in (0, 63, 64, 333, 699):
+        rm, rv, _, _ = orc.structured_sate(smp[s], c["X"], c["T"], c["Y"], c["doTs"])
+        assert np.allclose(ms[s], rm, rtol=1e-9, atol=1e-14) and np.allclose(vs[s], rv, rtol=1e-8, atol=1e-15)
+
+
+def test_c_abi_argument_errors(gp):
+    """Negative status = "argument #k is invalid" + gpslc_last_error text; no exception crosses the ABI."""
+    import ctypes as C
+    lib = gp.load_library()
+    h = C.c_void_p()
+    assert lib.gpslc_create(C.byref(h), 0, 0, 0, 0, 0) == -3          # n < 1
+    assert lib.gpslc_create(C.byref(h), 0, 10, 30, 5, 0) == -4        # nX + nU > 32
+    assert lib.gpslc_create(C.byref(h), 99, 10, 0, 0, 0) == -2        # no such device
+    ctx = gp.Context(10, 0, 0)
+    one = np.ones(1)
+    out = np.zeros(1)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    st = lib.gpslc_predict(ctx.h, 1, None, None, None, p(one), p(one), p(one), 1, p(one), 1e-10, 0, 0, None,
+                           p(out), p(out), None, None)
+    assert st == -1002 and b"set_data" in lib.gpslc_last_error(ctx.h)   # GPSLC_ERR_NODATA
+    ctx.set_data(None, np.zeros(10), np.zeros(10))
+    st = lib.gpslc_predict(ctx.h, 1, None, None, None, p(one), p(one), p(one), 0, p(one), 1e-10, 0, 0, None,
+                           p(out), p(out), None, None)
+    assert st == -9 and b"L < 1" in lib.gpslc_last_error(ctx.h)
+    with pytest.raises(gp.GPSLCError):
+        ctx.check(st)
+    # S = 0 is a no-op
+    assert lib.gpslc_predict(ctx.h, 0, None, None, None, None, None, None, 1, p(one), 1e-10, 0, 0, None,
+                             None, None, None, None) == 0

@@ -1,1 +1,2 @@
-for q in 16384 32768 65536 131072; do echo "GPSLC_UNITB_Q=$q"; GPSLC_UNITB_Q=$q timeout -k 10 300 python tools_unitb.py 2>&1 | tail -2; done
+mkdir -p gpurun_out
+timeout -k 10 600 python -m pytest tests -m gpu -q -x > gpurun_out/pytest11.log 2>&1; tail -12 gpurun_out/pytest11.log
