@@ -9,7 +9,7 @@ from .api import (  # noqa: F401
     Context, GPSLCObject, HyperParameters, PREDICTION_COVARIANCE_NOISE,
     rbfKernelLog, processCov, conditionalITE, ITEDistributions, ITEsamples, conditionalSATE,
     SATEDistributions, SATEsamples, sampleITE, sampleSATE, predictCounterfactualEffects,
-    summarizeEstimates, yLogpdf, predict, doTRange, getN, getNX, getNU, getNumPosteriorSamples,
+    summarizeEstimates, yLogpdf, gpLogpdf, mvnLogpdf, predict, doTRange, getN, getNX, getNU, getNumPosteriorSamples,
 )
 from . import synth  # noqa: F401
 from .sharded import predict_sharded, shard_range  # noqa: F401

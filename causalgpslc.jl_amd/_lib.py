@@ -56,6 +56,8 @@ SIGNATURES = {
     "gpslc_rbf_log": (C.c_int, [C.c_void_p, _D, _D, C.c_int64, C.c_int32, _D, C.c_int32, _D]),
     "gpslc_process_cov": (C.c_int, [C.c_void_p, _D, C.c_int64, C.c_double, C.c_double, _D]),
     "gpslc_y_logpdf": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D, _D, _D, _D, _D]),
+    "gpslc_gp_logpdf": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _D, C.c_int32, _D, _D, _D, _D, C.c_int32, _D]),
+    "gpslc_mvn_logpdf": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D]),
     "gpslc_predict": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D, _D, _D, C.c_int32, _D, C.c_double,
                                 C.c_int32, C.c_uint64, _D, _D, _D, _D, _D]),
     "gpslc_predict_dev": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D, _D, _D, C.c_int32, _D, C.c_double,

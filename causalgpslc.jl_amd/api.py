@@ -423,3 +423,52 @@ def yLogpdf(g: GPSLCObject, X_override=None):
     st = ctx.lib.gpslc_y_logpdf(ctx.h, S, U, _p(Xo), uy, xy, ty, ys, yn, _p(out))
     ctx.check(st)
     return out
+
+
+def gpLogpdf(F, LS, scale, noise, target, ctx: Optional[Context] = None):
+    """log N(target; 0, processCov(rbfKernelLog(F, F, LS), scale, noise)) on the GPU, for one parameter set
+    (F (n, nF), LS (nF,), scalars) or S of them (F (n, nF, S) or shared (n, nF); LS (nF, S); scale, noise (S,);
+    target (n, S) or shared (n,)): the :X => k => :X, :T / :logitT and :Y node scores of the reference's Gen
+    models (src/model_likelihood.jl:13-120)."""
+    scale = np.atleast_1d(np.asarray(scale, dtype=np.float64))
+    noise = np.atleast_1d(np.asarray(noise, dtype=np.float64))
+    S = scale.shape[0]
+    target = _f(target)
+    n = target.shape[0]
+    t_shared = 1 if target.ndim == 1 else 0
+    if F is None:
+        nF, Fa, f_shared, ls = 0, None, 1, None
+    else:
+        Fa = _f(F)
+        if Fa.ndim == 1:
+            Fa = Fa[:, None]
+        nF = Fa.shape[1]
+        f_shared = 1 if Fa.ndim == 2 else 0
+        ls = np.asfortranarray(np.asarray(LS, dtype=np.float64).reshape(nF, S, order="F"))
+    own = ctx is None
+    ctx = ctx or Context(n, 0, 0)
+    if own:
+        ctx.set_data(None, np.zeros(n), np.zeros(n))
+    out = np.empty(S)
+    st = ctx.lib.gpslc_gp_logpdf(ctx.h, S, nF, _p(Fa), f_shared, _p(ls), _p(scale), _p(noise), _p(target), t_shared,
+                                 _p(out))
+    ctx.check(st)
+    return out
+
+
+def mvnLogpdf(cov, x, covscale=None, ctx: Optional[Context] = None):
+    """log N(x_s; 0, covscale_s * cov): the :U => u => :U node scores (uCov = SigmaU * uNoise,
+    src/model_likelihood.jl:4-10, src/model_prior.jl:27-30)."""
+    cov = _f(cov)
+    n = cov.shape[0]
+    x = _f(x)
+    if x.ndim == 1:
+        x = x[:, None]
+    S = x.shape[1]
+    cs = None if covscale is None else np.ascontiguousarray(np.atleast_1d(covscale), dtype=np.float64)
+    own = ctx is None
+    ctx = ctx or Context(n, 0, 0)
+    out = np.empty(S)
+    st = ctx.lib.gpslc_mvn_logpdf(ctx.h, S, _p(cov), _p(cs), _p(x), _p(out))
+    ctx.check(st)
+    return out

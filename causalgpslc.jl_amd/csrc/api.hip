@@ -270,6 +270,10 @@ struct PredictIO {
     // ITEDistributions-style outputs (single level): MeanITEs S x n, CovITEs S x n x n
     double *MeanITEs = nullptr, *CovITEs = nullptr;
     int* info = nullptr;   // device, S
+    int nU = -1, nX = -1;            // feature counts of this call (default: the ctx's)
+    const double* Y = nullptr;       // right-hand side 0 (default: the ctx's Y) and its per-sample stride
+    long long y_sstride = 0;
+    bool p_shared_u = false;         // the feature block is shared by all samples (u_sstride stays 0)
 };
 
 int auto_batch(gpslc_ctx* c, int64_t S, size_t per_sample_bytes, size_t fixed_bytes) {
@@ -291,7 +295,12 @@ int auto_batch(gpslc_ctx* c, int64_t S, size_t per_sample_bytes, size_t fixed_by
 }
 
 // the chunked ensemble driver (device pointers everywhere)
-void run_predict(gpslc_ctx* c, const PredictIO& io) {
+void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
+    PredictIO io = io_in;
+    if (io.nU < 0) io.nU = c->nU;
+    if (io.nX < 0) io.nX = c->nX;
+    if (!io.Y) { io.Y = c->dY; io.y_sstride = 0; }
+    if (io.p.u_sstride == 0 && io.nU > 0 && io.p.U != nullptr && !io.p_shared_u) io.p.u_sstride = (long long)c->n * io.nU;
     ensure_streams(c);
     const int n = (int)c->n, nt = c->nt;
     const int L = io.L;
@@ -359,13 +368,13 @@ void run_predict(gpslc_ctx* c, const PredictIO& io) {
 
         GramArgs ga{};
         ga.X = io.X; ga.T = c->dT; ga.p = io.p; ga.s0 = s0;
-        ga.n = n; ga.nX = c->nX; ga.nU = c->nU; ga.nt = nt; ga.M = M; ga.part = part;
+        ga.n = n; ga.nX = io.nX; ga.nU = io.nU; ga.nt = nt; ga.M = M; ga.part = part;
         ga.with_sums = with_sums ? 1 : 0;
         ga.f32 = (c->flags & GPSLC_FLAG_FP32_KERNEL) ? 1 : 0;
         launch_gram(ga, nb, st);
 
         RhsArgs ra{};
-        ra.T = c->dT; ra.Y = c->dY; ra.tyLS = io.p.tyLS; ra.doT = io.doT; ra.s0 = s0;
+        ra.T = c->dT; ra.Y = io.Y; ra.y_sstride = io.y_sstride; ra.tyLS = io.p.tyLS; ra.doT = io.doT; ra.s0 = s0;
         ra.n = n; ra.nt = nt; ra.naug = naug; ra.L = with_sums ? L : 0; ra.with_sums = with_sums ? 1 : 0;
         ra.part = part; ra.bsum = bsum; ra.ksum = ksum; ra.sumdelta = sumdelta; ra.M = M;
         launch_rhs(ra, nb, st);
@@ -385,7 +394,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io) {
             const double* alpha = zwork + (long long)nb * Np;
             IteMeanArgs ia{};
             ia.X = io.X; ia.T = c->dT; ia.p = io.p; ia.s0 = s0; ia.S = io.S;
-            ia.n = n; ia.nX = c->nX; ia.nU = c->nU; ia.nt = nt; ia.L = L; ia.doT = io.doT; ia.alpha = alpha;
+            ia.n = n; ia.nX = io.nX; ia.nU = io.nU; ia.nt = nt; ia.L = L; ia.doT = io.doT; ia.alpha = alpha;
             ia.f32 = (c->flags & GPSLC_FLAG_FP32_KERNEL) ? 1 : 0;
             if (meanITE) {
                 ia.meanITE = meanITE; ia.si = 1; ia.ss = n; ia.sl = (long long)n * io.S;
@@ -413,7 +422,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io) {
                     TRef Ls = lower_ref(tiles + (long long)u0 * bstride, bstride);
                     DtArgs da{};
                     da.X = io.X; da.T = c->dT; da.p = io.p; da.s0 = s0 + u0;
-                    da.n = n; da.nX = c->nX; da.nU = c->nU; da.nt = nt; da.doT = hdoT[l];
+                    da.n = n; da.nX = io.nX; da.nU = io.nU; da.nt = nt; da.doT = hdoT[l];
                     da.pred_noise = io.pred_noise; da.W = W; da.Cm = Cm;
                     launch_dt_build(da, ub, st);
                     // W <- D L^-T (left-looking over tile columns)
@@ -796,6 +805,96 @@ int gpslc_y_logpdf(gpslc_ctx* c, int64_t S, const double* U, const double* X_or_
         const double l2pi = 1.8378770664093454835606594728112;
         for (int64_t s = 0; s < S; ++s) logpdf[s] = -0.5 * ((double)c->n * l2pi + ld[s] + q[s]);
         return first_info(c);
+    });
+}
+
+int gpslc_gp_logpdf(gpslc_ctx* c, int64_t S, int32_t nF, const double* F, int32_t f_shared, const double* ls,
+                    const double* scale, const double* noise, const double* target, int32_t t_shared,
+                    double* logpdf) {
+    if (!c) return -1;
+    if (S < 0) return bad_arg(c, 2, "S < 0");
+    if (nF < 0 || nF > 32) return bad_arg(c, 3, "nF must be in 0..32");
+    if (nF > 0 && (!F || !ls)) return bad_arg(c, 4, "F / ls must not be NULL when nF > 0");
+    if (S > 0 && (!scale || !noise)) return bad_arg(c, 7, "scale / noise must not be NULL");
+    if (S > 0 && !target) return bad_arg(c, 9, "target is NULL");
+    if (!logpdf) return bad_arg(c, 11, "logpdf is NULL");
+    if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
+    return guarded(c, [&]() {
+        const size_t n = (size_t)c->n;
+        DevBuf bF, bls, bsc, bno, btg, bty, bdo, old, oq, info;
+        const double* dF = nF ? up(bF, F, n * nF * (f_shared ? 1 : S)) : nullptr;
+        const double* dls = nF ? up(bls, ls, (size_t)nF * S) : nullptr;
+        const double* dsc = up(bsc, scale, S);
+        const double* dno = up(bno, noise, S);
+        const double* dtg = up(btg, target, n * (t_shared ? 1 : S));
+        std::vector<double> inf(S, INFINITY);        // tyLS = inf switches the treatment term off: e_ij = exp(-0) = 1
+        const double* dty = up(bty, inf.data(), S);
+        const double zero = 0.0;
+        const double* ddo = up(bdo, &zero, 1);
+        old.alloc(sizeof(double) * S);
+        oq.alloc(sizeof(double) * S);
+        info.alloc(sizeof(int) * S);
+        PredictIO io;
+        io.S = S;
+        io.p = SampleParams{dF, dls, nullptr, dty, dsc, dno, f_shared ? 0 : (long long)n * nF};
+        io.p_shared_u = f_shared != 0;
+        io.X = nullptr; io.nU = nF; io.nX = 0;
+        io.Y = dtg; io.y_sstride = t_shared ? 0 : (long long)n;
+        io.L = 0; io.doT = ddo; io.logdet = old.as<double>(); io.quad = oq.as<double>(); io.info = info.as<int>();
+        run_predict(c, io);
+        std::vector<double> ld(S), q(S);
+        HC(hipMemcpy(ld.data(), old.p, sizeof(double) * S, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(q.data(), oq.p, sizeof(double) * S, hipMemcpyDeviceToHost));
+        const double l2pi = 1.8378770664093454835606594728112;
+        for (int64_t s = 0; s < S; ++s) logpdf[s] = -0.5 * ((double)c->n * l2pi + ld[s] + q[s]);
+        return first_info(c);
+    });
+}
+
+int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* covscale, const double* x,
+                     double* logpdf) {
+    if (!c) return -1;
+    if (S < 0) return bad_arg(c, 2, "S < 0");
+    if (!cov) return bad_arg(c, 3, "cov is NULL");
+    if (S > 0 && !x) return bad_arg(c, 5, "x is NULL");
+    if (!logpdf) return bad_arg(c, 6, "logpdf is NULL");
+    if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
+    return guarded(c, [&]() {
+        ensure_streams(c);
+        const int n = (int)c->n, nt = c->nt;
+        const int naug = (int)((S + GP_TS - 1) / GP_TS);
+        const int ntot = nt + naug;
+        const long long tiles_per = (long long)ntot * (ntot + 1) / 2;
+        DevBuf bcov, bx, tiles, inv, old, oq, info;
+        const double* dcov = up(bcov, cov, (size_t)n * n);
+        const double* dx = up(bx, x, (size_t)n * S);
+        tiles.alloc((size_t)tiles_per * GP_TSQ * 8);
+        inv.alloc((size_t)nt * GP_TSQ * 8);
+        old.alloc(8); oq.alloc(sizeof(double) * S); info.alloc(sizeof(int));
+        hipStream_t st = c->streams[0];
+        HC(hipMemsetAsync(info.p, 0, sizeof(int), st));
+        TRef M = lower_ref(tiles.as<double>(), tiles_per * GP_TSQ);
+        launch_dense_load(DenseLoadArgs{dcov, n, nt, M}, st);
+        launch_rows_rhs(RowsRhsArgs{dx, S, n, nt, naug, M}, st);
+        potrf_tiles(c, M, nt, ntot, inv.as<double>(), (long long)nt * GP_TSQ, info.as<int>(), 0, 1, st,
+                    naug == 1 ? (int)S : 0);
+        launch_quad_rows(QuadRowsArgs{M, n, nt, naug, S, old.as<double>(), oq.as<double>()}, st);
+        HC(hipStreamSynchronize(st));
+        HC(hipGetLastError());
+        if (c->flags & GPSLC_FLAG_PROFILE) prof_collect(c);
+        double ld = 0;
+        std::vector<double> q(S);
+        int hinfo = 0;
+        HC(hipMemcpy(&ld, old.p, 8, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(q.data(), oq.p, sizeof(double) * S, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost));
+        c->last_info.assign(S, hinfo);
+        const double l2pi = 1.8378770664093454835606594728112;
+        for (int64_t s = 0; s < S; ++s) {
+            const double sc = covscale ? covscale[s] : 1.0;
+            logpdf[s] = -0.5 * ((double)n * l2pi + (double)n * std::log(sc) + ld + q[s] / sc);
+        }
+        return hinfo;
     });
 }
 

@@ -54,6 +54,7 @@ struct SampleParams {
     const double* tyLS;    // S
     const double* yScale;  // S
     const double* yNoise;  // S
+    long long u_sstride;   // doubles between the U blocks of consecutive samples (n*nU; 0 = shared)
 };
 
 struct GramArgs {
@@ -76,6 +77,7 @@ void launch_gram(const GramArgs& g, int nbatch, hipStream_t st);
 
 struct RhsArgs {
     const double* T; const double* Y; const double* tyLS; const double* doT;
+    long long y_sstride;   // right-hand side 0 of sample s is Y + s*y_sstride (0 = shared)
     long long s0; int n, nt, naug, L; int with_sums;
     const double* part; double* bsum; double* ksum; double* sumdelta;  // bsum/ksum [b][Np], sumdelta [b][L]
     TRef M;
@@ -133,3 +135,11 @@ struct DrawArgs {
     double* out;          // L x n x (S*spp)
 };
 void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st);
+
+// generic multivariate-normal pieces (U-prior node and friends)
+struct DenseLoadArgs { const double* cov; int n, nt; TRef M; };   // column-major n x n -> lower tiles
+void launch_dense_load(const DenseLoadArgs& a, hipStream_t st);
+struct RowsRhsArgs { const double* x; long long S; int n, nt, naug; TRef M; };   // rows q = x[:, q]
+void launch_rows_rhs(const RowsRhsArgs& a, hipStream_t st);
+struct QuadRowsArgs { TRef M; int n, nt, naug; long long S; double* logdet; double* quad; };
+void launch_quad_rows(const QuadRowsArgs& a, hipStream_t st);

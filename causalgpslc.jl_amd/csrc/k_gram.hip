@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
         const int f = idx >> 7, r = idx & 127;
         const double* src;
         double l;
-        if (f < g.nU) { src = g.p.U + (s * g.nU + f) * (long long)n; l = g.p.uyLS[s * g.nU + f]; }
+        if (f < g.nU) { src = g.p.U + s * g.p.u_sstride + (long long)f * n; l = g.p.uyLS[s * g.nU + f]; }
         else { src = g.X + (long long)(f - g.nU) * n; l = g.p.xyLS[s * g.nX + (f - g.nU)]; }
         const double il = 1.0 / l;
         fr[f * GP_TS + r] = (RT)((gi0 + r < n) ? src[gi0 + r] * il : 0.0);
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void rhs_tiles_kernel(RhsArgs a) {
         const int gj = j * GP_TS + c;         // instance index
         double v = 0.0;
         if (gj < a.n) {
-            if (gq == 0) v = a.Y[gj];
+            if (gq == 0) v = a.Y[s * a.y_sstride + gj];
             else if (gq <= a.L) {
                 const double dt = a.T[gj] - a.doT[gq - 1];
                 const double r = gp_exp_neg(-((dt * dt) * wt));
@@ -339,4 +339,68 @@ void launch_process_cov(const double* in, long long n, double scale, double nois
     const long long tot = n * n;
     hipLaunchKernelGGL(process_cov_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, in, n,
                        scale, noise, out);
+}
+
+// ---------------------------------------------------------------------------------------
+// Generic MvNormal pieces: a dense column-major covariance into lower tiles (identity on the
+// padding), S right-hand-side vectors as augmented rows, and the per-row quadratic forms.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_load_kernel(DenseLoadArgs a) {
+    int ti, tj;
+    {
+        const int t = blockIdx.x;
+        int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((long long)(r + 1) * (r + 2) / 2 <= t) ++r;
+        while ((long long)r * (r + 1) / 2 > t) --r;
+        ti = r; tj = t - r * (r + 1) / 2;
+    }
+    double* tile = tref_tile(a.M, 0, ti, tj);
+    for (int idx = threadIdx.x; idx < GP_TSQ; idx += 256) {
+        const int c = idx >> 7, r = idx & 127;
+        const long long gi = (long long)ti * GP_TS + r, gj = (long long)tj * GP_TS + c;
+        double v;
+        if (gi < a.n && gj < a.n) v = a.cov[gi + (long long)a.n * gj];
+        else v = (gi == gj) ? 1.0 : 0.0;
+        tile[idx] = v;
+    }
+}
+void launch_dense_load(const DenseLoadArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(dense_load_kernel, dim3(a.nt * (a.nt + 1) / 2), dim3(256), 0, st, a);
+}
+
+// tile (nt + au, j): row q of the augmented block = x[:, 128 au + q] (zero beyond S and on the padding);
+// aug x aug tiles zero.  grid (nt + naug, naug)
+__global__ __launch_bounds__(256) void rows_rhs_kernel(RowsRhsArgs a) {
+    const int j = blockIdx.x, au = blockIdx.y;
+    if (j > a.nt + au) return;
+    double* tile = tref_tile(a.M, 0, a.nt + au, j);
+    for (int idx = threadIdx.x; idx < GP_TSQ; idx += 256) {
+        const int c = idx >> 7, q = idx & 127;
+        const long long gq = (long long)au * GP_TS + q, gj = (long long)j * GP_TS + c;
+        double v = 0.0;
+        if (j < a.nt && gq < a.S && gj < a.n) v = a.x[gj + (long long)a.n * gq];
+        tile[idx] = v;
+    }
+}
+void launch_rows_rhs(const RowsRhsArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(rows_rhs_kernel, dim3(a.nt + a.naug, a.naug), dim3(256), 0, st, a);
+}
+
+__global__ __launch_bounds__(256) void quad_rows_kernel(QuadRowsArgs a) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int i = tid; i < a.n; i += 256) {
+        const double* dt = tref_tile(a.M, 0, i >> 7, i >> 7);
+        acc += log(dt[(i & 127) * GP_TS + (i & 127)]);
+    }
+    const double ld = 2.0 * block_sum_256(acc, red);
+    if (tid == 0) a.logdet[0] = ld;
+    for (long long q = tid; q < a.S; q += 256) {
+        const int au = (int)(q >> 7), qq = (int)(q & 127);
+        a.quad[q] = -tref_tile(a.M, 0, a.nt + au, a.nt + au)[qq * GP_TS + qq];
+    }
+}
+void launch_quad_rows(const QuadRowsArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(quad_rows_kernel, dim3(1), dim3(256), 0, st, a);
 }

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     const int gi = ib * GP_TS + r;
 
     auto feat_src = [&](int f) -> const double* {
-        return (f < a.nU) ? a.p.U + (s * a.nU + f) * (long long)n : a.X + (long long)(f - a.nU) * n;
+        return (f < a.nU) ? a.p.U + s * a.p.u_sstride + (long long)f * n : a.X + (long long)(f - a.nU) * n;
     };
     auto feat_il = [&](int f) -> double {
         return 1.0 / ((f < a.nU) ? a.p.uyLS[s * a.nU + f] : a.p.xyLS[s * a.nX + (f - a.nU)]);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void dt_build_kernel(DtArgs a) {
     const double wt = 1.0 / (tl * tl);
     for (int idx = tid; idx < F * GP_TS; idx += 256) {
         const int f = idx >> 7, r = idx & 127;
-        const double* src = (f < a.nU) ? a.p.U + (s * a.nU + f) * (long long)n
+        const double* src = (f < a.nU) ? a.p.U + s * a.p.u_sstride + (long long)f * n
                                        : a.X + (long long)(f - a.nU) * n;
         const double il = 1.0 / ((f < a.nU) ? a.p.uyLS[s * a.nU + f] : a.p.xyLS[s * a.nX + (f - a.nU)]);
         fr[idx] = (gi0 + r < n) ? src[gi0 + r] * il : 0.0;

@@ -87,6 +87,25 @@ int gpslc_y_logpdf(gpslc_ctx* ctx, int64_t S, const double* U, const double* X_o
                    const double* uyLS, const double* xyLS, const double* tyLS,
                    const double* yScale, const double* yNoise, double* logpdf /* S */);
 
+/* ---- the other Gaussian-process nodes of the Gen models -------------- */
+
+/* log N(target; 0, scale * exp.(rbfKernelLog(F, F, ls)) + noise * I) for S parameter sets: the score of
+ *   :X => k => :X   generateXfromU    F = U,       ls = uxLS[k, :]           (src/model_likelihood.jl:13-22)
+ *   :T / :logitT    generate*TfromUX  F = [U | X], ls = [utLS ; xtLS]        (src/model_likelihood.jl:25-80)
+ *   :Y              generateYfrom*    F = [U | X | T]                        (:83-120; gpslc_y_logpdf is the
+ *                                                                             specialised form that shares X, T, Y)
+ * F is n x nF x S (f_shared = 0) or n x nF shared by all sets (f_shared = 1); ls nF x S; scale, noise S;
+ * target n x S (t_shared = 0) or n (t_shared = 1).  nF <= 32. */
+int gpslc_gp_logpdf(gpslc_ctx* ctx, int64_t S, int32_t nF, const double* F, int32_t f_shared,
+                    const double* ls, const double* scale, const double* noise, const double* target,
+                    int32_t t_shared, double* logpdf /* S */);
+
+/* log N(x_s; 0, covscale_s * cov) for S vectors and one dense n x n covariance: the :U => u => :U nodes
+ * (generateUfromSigmaU, src/model_likelihood.jl:4-10 with uCov = SigmaU * uNoise; generateU,
+ * src/model_prior.jl:27-30).  cov is factorised once per call; covscale may be NULL (= 1). */
+int gpslc_mvn_logpdf(gpslc_ctx* ctx, int64_t S, const double* cov, const double* covscale /* S */,
+                     const double* x /* n x S */, double* logpdf /* S */);
+
 /* ---- src/estimation.jl, src/driver.jl, src/prediction.jl ------------------------------ */
 
 /* The ensemble driver: everything sampleITE / sampleSATE / predictCounterfactualEffects

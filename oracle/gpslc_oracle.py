@@ -526,3 +526,41 @@ def philox_normals(seed: int, stream: int, count: int):
     rad = np.sqrt(-2.0 * np.log(u1))
     ang = 2.0 * math.pi * u2
     return np.where((e & np.uint64(1)) == 0, rad * np.cos(ang), rad * np.sin(ang))
+
+
+# ----------------------------------------------------------------------------
+# the other Gaussian-process nodes of the Gen models
+# ----------------------------------------------------------------------------
+
+
+def mvnormal_logpdf(x, cov):
+    """Gen ``mvnormal(zeros(n), cov)`` score = logpdf(MvNormal(0, Symmetric(cov)), x) (Distributions/PDMats:
+    Cholesky, -1/2 (n log 2pi + logdet + x' cov^-1 x))."""
+    x = np.asarray(x, dtype=np.float64)
+    L = np.linalg.cholesky(np.asarray(cov, dtype=np.float64))
+    z = sla.solve_triangular(L, x, lower=True, check_finite=False)
+    n = x.shape[0]
+    return float(-0.5 * (n * math.log(2 * math.pi) + 2 * np.sum(np.log(np.diag(L))) + z @ z))
+
+
+def x_node_logpdf(U, uxLS_k, xScale_k, xNoise_k, X_k):
+    """:X => k => :X of generateXfromU (src/model_likelihood.jl:13-22):
+    xCov_k = processCov(rbfKernelLog(U, U, uxLS[k, :]), xScale[k], xNoise[k])."""
+    return mvnormal_logpdf(X_k, process_cov(rbf_kernel_log(U, U, uxLS_k), xScale_k, xNoise_k))
+
+
+def t_node_logpdf(U, X, utLS, xtLS, tScale, tNoise, T):
+    """:T (real) / :logitT (binary) of generate{Real,Binary}Tfrom{UX,U,X}
+    (src/model_likelihood.jl:25-80): cov = processCov(utCovLog + xtCovLog, tScale, tNoise)."""
+    n = np.asarray(T).shape[0]
+    acc = np.zeros((n, n))
+    if U is not None:
+        acc = acc + rbf_kernel_log(U, U, utLS)
+    if X is not None:
+        acc = acc + rbf_kernel_log(X, X, xtLS)
+    return mvnormal_logpdf(T, process_cov(acc, tScale, tNoise))
+
+
+def u_node_logpdf(SigmaU, uNoise, U_k):
+    """:U => u => :U of generateUfromSigmaU (src/model_likelihood.jl:4-10): uCov = SigmaU * uNoise."""
+    return mvnormal_logpdf(U_k, np.asarray(SigmaU) * uNoise)

@@ -1,0 +1,86 @@
+"""the other Gaussian-process nodes of the reference's Gen models on the GPU —
+:X => k => :X, :T / :logitT (src/model_likelihood.jl:13-80) and :U => u => :U (:4-10) — against the
+oracle's restatement of Gen's mvnormal score."""
+import numpy as np
+import pytest
+
+import gpslc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(n, nU, nX, seed):
+    rng = np.random.default_rng(seed)
+    U = rng.standard_normal((n, nU))
+    X = rng.standard_normal((n, nX))
+    T = rng.standard_normal(n)
+    return rng, U, X, T
+
+
+@pytest.mark.parametrize("n", [10, 150, 300])
+def test_x_nodes_given_u(gp, n):
+    nU, nX = 2, 3
+    rng, U, X, _ = _data(n, nU, nX, n)
+    uxLS = rng.uniform(0.5, 2.0, (nX, nU))
+    xScale = rng.uniform(0.5, 2.0, nX)
+    xNoise = rng.uniform(0.3, 1.5, nX)
+    # the nX nodes as ONE call: shared features U, one parameter set per covariate, targets X[:, k]
+    out = gp.gpLogpdf(U, uxLS.T, xScale, xNoise, X)
+    ref = [orc.x_node_logpdf(U, uxLS[k], xScale[k], xNoise[k], X[:, k]) for k in range(nX)]
+    assert np.allclose(out, ref, rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("binary", [False, True])
+@pytest.mark.parametrize("n", [24, 260])
+def test_t_node_given_u_and_x(gp, n, binary):
+    nU, nX = 2, 4
+    rng, U, X, T = _data(n, nU, nX, 100 + n)
+    target = rng.standard_normal(n) if binary else T      # :logitT for binary treatments, :T otherwise
+    utLS, xtLS = rng.uniform(0.5, 2.0, nU), rng.uniform(0.5, 2.0, nX)
+    tScale, tNoise = 1.3, 0.7
+    out = gp.gpLogpdf(np.hstack([U, X]), np.concatenate([utLS, xtLS]), tScale, tNoise, target)
+    ref = orc.t_node_logpdf(U, X, utLS, xtLS, tScale, tNoise, target)
+    assert np.allclose(out, [ref], rtol=1e-11, atol=1e-9)
+    # no-covariates and no-confounders variants (generateRealTfromU / generateRealTfromX)
+    out = gp.gpLogpdf(U, utLS, tScale, tNoise, target)
+    assert np.allclose(out, [orc.t_node_logpdf(U, None, utLS, None, tScale, tNoise, target)], rtol=1e-11, atol=1e-9)
+    out = gp.gpLogpdf(X, xtLS, tScale, tNoise, target)
+    assert np.allclose(out, [orc.t_node_logpdf(None, X, None, xtLS, tScale, tNoise, target)], rtol=1e-11, atol=1e-9)
+
+
+def test_y_node_as_generic_node_matches_specialised_entry(gp):
+    """The :Y node is the generic node with T as one more feature (src/model_likelihood.jl:83-91)."""
+    import cases
+    c = cases.make_case(200, "UX", False, S=3, seed=12)
+    obj = cases.gpslc_object(gp, c)
+    spec = gp.yLogpdf(obj)
+    n, S = 200, 3
+    F = np.concatenate([c["U"], np.repeat(c["X"][:, :, None], S, axis=2), np.repeat(c["T"][:, None, None], S, axis=2)],
+                       axis=1)
+    ls = np.vstack([c["uyLS"], c["xyLS"], c["tyLS"][None, :]])
+    gen = gp.gpLogpdf(F, ls, c["yScale"], c["yNoise"], c["Y"])
+    assert np.allclose(gen, spec, rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("eps", [1e-3, 1e-6])
+def test_u_prior_nodes(gp, eps):
+    """uCov = SigmaU * uNoise with SigmaU = generateSigmaU(object sizes) (src/utils.jl:17-33).  With the
+    reference's default sigmaUNoise = 1e-13 the matrix is numerically singular (cond ~ 1e14) and ANY
+    Cholesky returns rounding noise, so parity is checked at better-conditioned jitters."""
+    sizes = [25, 40, 35, 30, 20]
+    n = sum(sizes)
+    SigmaU = orc.generate_sigma_u(sizes, eps, 1.0)
+    rng = np.random.default_rng(4)
+    nU, uNoise = 3, 1.7
+    Lc = np.linalg.cholesky(SigmaU * uNoise)
+    Uk = Lc @ rng.standard_normal((n, nU))          # plausible draws: object-constant + tiny within-object noise
+    out = gp.mvnLogpdf(SigmaU, Uk, covscale=np.full(nU, uNoise))
+    ref = [orc.u_node_logpdf(SigmaU, uNoise, Uk[:, k]) for k in range(nU)]
+    tol = 1e-6 if eps < 1e-4 else 1e-9              # the quadratic form is amplified by 1/eps
+    assert np.allclose(out, ref, rtol=tol, atol=1e-6)
+
+
+def test_mvn_not_positive_definite(gp):
+    cov = np.ones((6, 6))
+    with pytest.raises(gp.PosDefException):
+        gp.mvnLogpdf(cov, np.ones(6))

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests -m gpu -q -x > gpurun_out/pytest11.log 2>&1; tail -12 gpurun_out/pytest11.log
+timeout -k 10 600 python -m pytest tests -m gpu -q -x > gpurun_out/pytest12.log 2>&1; tail -12 gpurun_out/pytest12.log
