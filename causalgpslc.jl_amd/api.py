@@ -458,17 +458,19 @@ def gpLogpdf(F, LS, scale, noise, target, ctx: Optional[Context] = None):
 
 def mvnLogpdf(cov, x, covscale=None, ctx: Optional[Context] = None):
     """log N(x_s; 0, covscale_s * cov): the :U => u => :U node scores (uCov = SigmaU * uNoise,
-    src/model_likelihood.jl:4-10, src/model_prior.jl:27-30)."""
-    cov = _f(cov)
-    n = cov.shape[0]
+    src/model_likelihood.jl:4-10, src/model_prior.jl:27-30).  ``cov=None`` re-uses the factor cached in
+    ``ctx`` by an earlier call (SigmaU is constant for a data set)."""
     x = _f(x)
     if x.ndim == 1:
         x = x[:, None]
-    S = x.shape[1]
+    n, S = x.shape
+    covf = None
+    if cov is not None:
+        cov = np.asarray(cov, dtype=np.float64)
+        covf = cov if cov.flags.f_contiguous or cov.flags.c_contiguous else np.ascontiguousarray(cov)  # symmetric
     cs = None if covscale is None else np.ascontiguousarray(np.atleast_1d(covscale), dtype=np.float64)
-    own = ctx is None
     ctx = ctx or Context(n, 0, 0)
     out = np.empty(S)
-    st = ctx.lib.gpslc_mvn_logpdf(ctx.h, S, _p(cov), _p(cs), _p(x), _p(out))
+    st = ctx.lib.gpslc_mvn_logpdf(ctx.h, S, _p(covf), _p(cs), _p(x), _p(out))
     ctx.check(st)
     return out

@@ -64,6 +64,11 @@ struct gpslc_ctx {
     Arena scratch;                 // call-level buffers (host-pointer entry points, info, ...)
     std::string err;
     std::vector<int32_t> last_info;
+    // cached factor of the last dense covariance given to gpslc_mvn_logpdf (SigmaU is constant per data set)
+    double *mvn_tiles = nullptr, *mvn_inv = nullptr;
+    double mvn_logdet = 0.0;
+    int mvn_info = 0;
+    bool mvn_valid = false;
     // L2-blocked visiting orders of the lower-triangular tile sets, keyed by the triangle size m
     std::vector<unsigned short*> tri_order;
     int order_block = 8;
@@ -601,6 +606,8 @@ int gpslc_destroy(gpslc_ctx* c) {
     if (c->scratch.base) (void)hipFree(c->scratch.base);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto p : c->tri_order) if (p) (void)hipFree(p);
+    if (c->mvn_tiles) (void)hipFree(c->mvn_tiles);
+    if (c->mvn_inv) (void)hipFree(c->mvn_inv);
     if (c->dX) (void)hipFree(c->dX);
     if (c->dT) (void)hipFree(c->dT);
     if (c->dY) (void)hipFree(c->dY);
@@ -855,46 +862,77 @@ int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* c
                      double* logpdf) {
     if (!c) return -1;
     if (S < 0) return bad_arg(c, 2, "S < 0");
-    if (!cov) return bad_arg(c, 3, "cov is NULL");
+    if (!cov && !c->mvn_valid) return bad_arg(c, 3, "cov is NULL and no factor is cached");
     if (S > 0 && !x) return bad_arg(c, 5, "x is NULL");
-    if (!logpdf) return bad_arg(c, 6, "logpdf is NULL");
-    if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
+    if (S > 0 && !logpdf) return bad_arg(c, 6, "logpdf is NULL");
     return guarded(c, [&]() {
         ensure_streams(c);
         const int n = (int)c->n, nt = c->nt;
-        const int naug = (int)((S + GP_TS - 1) / GP_TS);
-        const int ntot = nt + naug;
-        const long long tiles_per = (long long)ntot * (ntot + 1) / 2;
-        DevBuf bcov, bx, tiles, inv, old, oq, info;
-        const double* dcov = up(bcov, cov, (size_t)n * n);
-        const double* dx = up(bx, x, (size_t)n * S);
-        tiles.alloc((size_t)tiles_per * GP_TSQ * 8);
-        inv.alloc((size_t)nt * GP_TSQ * 8);
-        old.alloc(8); oq.alloc(sizeof(double) * S); info.alloc(sizeof(int));
+        const long long nlow = (long long)nt * (nt + 1) / 2;
         hipStream_t st = c->streams[0];
-        HC(hipMemsetAsync(info.p, 0, sizeof(int), st));
-        TRef M = lower_ref(tiles.as<double>(), tiles_per * GP_TSQ);
-        launch_dense_load(DenseLoadArgs{dcov, n, nt, M}, st);
-        launch_rows_rhs(RowsRhsArgs{dx, S, n, nt, naug, M}, st);
-        potrf_tiles(c, M, nt, ntot, inv.as<double>(), (long long)nt * GP_TSQ, info.as<int>(), 0, 1, st,
-                    naug == 1 ? (int)S : 0);
-        launch_quad_rows(QuadRowsArgs{M, n, nt, naug, S, old.as<double>(), oq.as<double>()}, st);
+        if (cov) {   // factor once, keep L and the inverted diagonal blocks in the context
+            c->mvn_valid = false;
+            if (!c->mvn_tiles) HC(hipMalloc((void**)&c->mvn_tiles, (size_t)nlow * GP_TSQ * 8));
+            if (!c->mvn_inv) HC(hipMalloc((void**)&c->mvn_inv, (size_t)nt * GP_TSQ * 8));
+            DevBuf bcov, old, oq, info;
+            const double* dcov = up(bcov, cov, (size_t)n * n);
+            old.alloc(8); oq.alloc(8); info.alloc(sizeof(int));
+            HC(hipMemsetAsync(info.p, 0, sizeof(int), st));
+            TRef M = lower_ref(c->mvn_tiles, nlow * GP_TSQ);
+            launch_dense_load(DenseLoadArgs{dcov, n, nt, M}, st);
+            potrf_tiles(c, M, nt, nt, c->mvn_inv, (long long)nt * GP_TSQ, info.as<int>(), 0, 1, st);
+            launch_quad_rows(QuadRowsArgs{M, n, nt, 0, 0, old.as<double>(), oq.as<double>()}, st);
+            HC(hipStreamSynchronize(st));
+            HC(hipGetLastError());
+            HC(hipMemcpy(&c->mvn_logdet, old.p, 8, hipMemcpyDeviceToHost));
+            HC(hipMemcpy(&c->mvn_info, info.p, sizeof(int), hipMemcpyDeviceToHost));
+            c->mvn_valid = true;
+        }
+        c->last_info.assign((size_t)S, c->mvn_info);
+        if (S == 0 || c->mvn_info != 0) {
+            for (int64_t s = 0; s < S; ++s) logpdf[s] = NAN;
+            return c->mvn_info;
+        }
+        // z_s = L^-1 x_s for all S vectors: rows of W = X^T L^-T, tile-level left-looking solve
+        const int naug = (int)((S + GP_TS - 1) / GP_TS);
+        DevBuf bx, wt, oq;
+        const double* dx = up(bx, x, (size_t)n * S);
+        wt.alloc((size_t)naug * nt * GP_TSQ * 8);
+        oq.alloc(sizeof(double) * S);
+        TRef W = rect_ref(wt.as<double>(), (long long)naug * nt * GP_TSQ, nt);
+        TRef Ls = lower_ref(c->mvn_tiles, nlow * GP_TSQ);
+        TRef invref = TRef{c->mvn_inv, (long long)nt * GP_TSQ, 1, 0, 0, 0};
+        launch_rows_rhs(RowsRhsArgs{dx, S, n, nt, naug, W, 0, 1}, st);
+        const int short_rows = naug == 1 ? (int)S : 0;
+        // right-looking: z_k = w_k inv(L_kk)^T, then every remaining column block in parallel
+        for (int k = 0; k < nt; ++k) {
+            GemmArgs g{};
+            g.A = W; g.B = invref; g.C = W;
+            g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = naug; g.mj = 1;
+            g.k0 = k; g.k1 = k + 1; g.accumulate = 0; g.nbatch = 1; g.ntiles = naug;
+            g.short_row0 = 0; g.short_rows = short_rows;
+            gemm(c, g, st);
+            if (k + 1 < nt) {   // W(:, j) -= W(:, k) L(j, k)^T for j > k
+                GemmArgs u{};
+                u.A = W; u.B = Ls; u.C = W;
+                u.shape = 1; u.i0 = 0; u.j0 = k + 1; u.mi = naug; u.mj = nt - k - 1;
+                u.k0 = k; u.k1 = k + 1; u.accumulate = 1; u.nbatch = 1; u.ntiles = naug * (nt - k - 1);
+                u.short_row0 = 0; u.short_rows = short_rows;
+                gemm(c, u, st);
+            }
+        }
+        launch_row_norms(RowNormArgs{W, nt, naug, S, oq.as<double>()}, st);
         HC(hipStreamSynchronize(st));
         HC(hipGetLastError());
         if (c->flags & GPSLC_FLAG_PROFILE) prof_collect(c);
-        double ld = 0;
         std::vector<double> q(S);
-        int hinfo = 0;
-        HC(hipMemcpy(&ld, old.p, 8, hipMemcpyDeviceToHost));
         HC(hipMemcpy(q.data(), oq.p, sizeof(double) * S, hipMemcpyDeviceToHost));
-        HC(hipMemcpy(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost));
-        c->last_info.assign(S, hinfo);
         const double l2pi = 1.8378770664093454835606594728112;
         for (int64_t s = 0; s < S; ++s) {
             const double sc = covscale ? covscale[s] : 1.0;
-            logpdf[s] = -0.5 * ((double)n * l2pi + (double)n * std::log(sc) + ld + q[s] / sc);
+            logpdf[s] = -0.5 * ((double)n * l2pi + (double)n * std::log(sc) + c->mvn_logdet + q[s] / sc);
         }
-        return hinfo;
+        return GPSLC_OK;
     });
 }
 

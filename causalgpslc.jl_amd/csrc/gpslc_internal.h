@@ -139,7 +139,9 @@ void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st);
 // generic multivariate-normal pieces (U-prior node and friends)
 struct DenseLoadArgs { const double* cov; int n, nt; TRef M; };   // column-major n x n -> lower tiles
 void launch_dense_load(const DenseLoadArgs& a, hipStream_t st);
-struct RowsRhsArgs { const double* x; long long S; int n, nt, naug; TRef M; };   // rows q = x[:, q]
+struct RowsRhsArgs { const double* x; long long S; int n, nt, naug; TRef M; int row0; int rect; };   // rows q = x[:, q]
 void launch_rows_rhs(const RowsRhsArgs& a, hipStream_t st);
 struct QuadRowsArgs { TRef M; int n, nt, naug; long long S; double* logdet; double* quad; };
+struct RowNormArgs { TRef W; int nt, naug; long long S; double* quad; };   // quad[q] = ||row q of W||^2
+void launch_row_norms(const RowNormArgs& a, hipStream_t st);
 void launch_quad_rows(const QuadRowsArgs& a, hipStream_t st);

@@ -372,8 +372,8 @@ void launch_dense_load(const DenseLoadArgs& a, hipStream_t st) {
 // aug x aug tiles zero.  grid (nt + naug, naug)
 __global__ __launch_bounds__(256) void rows_rhs_kernel(RowsRhsArgs a) {
     const int j = blockIdx.x, au = blockIdx.y;
-    if (j > a.nt + au) return;
-    double* tile = tref_tile(a.M, 0, a.nt + au, j);
+    if (a.rect ? (j >= a.nt) : (j > a.nt + au)) return;
+    double* tile = tref_tile(a.M, 0, a.row0 + au, j);
     for (int idx = threadIdx.x; idx < GP_TSQ; idx += 256) {
         const int c = idx >> 7, q = idx & 127;
         const long long gq = (long long)au * GP_TS + q, gj = (long long)j * GP_TS + c;
@@ -401,6 +401,24 @@ __global__ __launch_bounds__(256) void quad_rows_kernel(QuadRowsArgs a) {
         a.quad[q] = -tref_tile(a.M, 0, a.nt + au, a.nt + au)[qq * GP_TS + qq];
     }
 }
+// quad[q] = sum over the tile row's entries of W(au, j)[q][c]^2; lanes run along q (contiguous)
+__global__ __launch_bounds__(128) void row_norms_kernel(RowNormArgs a) {
+    const int au = blockIdx.x, q = threadIdx.x;
+    double acc = 0.0;
+    for (int j = 0; j < a.nt; ++j) {
+        const double* t = tref_tile(a.W, 0, au, j);
+        for (int c = 0; c < GP_TS; ++c) {
+            const double v = t[c * GP_TS + q];
+            acc = fma(v, v, acc);
+        }
+    }
+    const long long gq = (long long)au * GP_TS + q;
+    if (gq < a.S) a.quad[gq] = acc;
+}
+void launch_row_norms(const RowNormArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(row_norms_kernel, dim3(a.naug), dim3(128), 0, st, a);
+}
+
 void launch_quad_rows(const QuadRowsArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(quad_rows_kernel, dim3(1), dim3(256), 0, st, a);
 }

@@ -102,7 +102,9 @@ int gpslc_gp_logpdf(gpslc_ctx* ctx, int64_t S, int32_t nF, const double* F, int3
 
 /* log N(x_s; 0, covscale_s * cov) for S vectors and one dense n x n covariance: the :U => u => :U nodes
  * (generateUfromSigmaU, src/model_likelihood.jl:4-10 with uCov = SigmaU * uNoise; generateU,
- * src/model_prior.jl:27-30).  cov is factorised once per call; covscale may be NULL (= 1). */
+ * src/model_prior.jl:27-30).  A non-NULL cov is factorised and the factor cached in the ctx (SigmaU is
+ * constant for a data set); cov = NULL re-uses the cached factor, so one evaluation costs a tiled
+ * forward solve only.  S = 0 with a non-NULL cov just (re)factorises.  covscale may be NULL (= 1). */
 int gpslc_mvn_logpdf(gpslc_ctx* ctx, int64_t S, const double* cov, const double* covscale /* S */,
                      const double* x /* n x S */, double* logpdf /* S */);
 

@@ -78,6 +78,13 @@ def test_u_prior_nodes(gp, eps):
     ref = [orc.u_node_logpdf(SigmaU, uNoise, Uk[:, k]) for k in range(nU)]
     tol = 1e-6 if eps < 1e-4 else 1e-9              # the quadratic form is amplified by 1/eps
     assert np.allclose(out, ref, rtol=tol, atol=1e-6)
+    # cached factor: a second evaluation with cov=None (what an MCMC step over uNoise / U does)
+    ctx = gp.Context(n, 0, 0)
+    gp.mvnLogpdf(SigmaU, Uk[:, :0].reshape(n, 0), ctx=ctx)          # factor only
+    out2 = gp.mvnLogpdf(None, Uk, covscale=np.full(nU, uNoise), ctx=ctx)
+    assert np.allclose(out2, ref, rtol=tol, atol=1e-6)
+    out3 = gp.mvnLogpdf(None, Uk[:, 1], covscale=[2.5], ctx=ctx)
+    assert np.allclose(out3, [orc.u_node_logpdf(SigmaU, 2.5, Uk[:, 1])], rtol=tol, atol=1e-6)
 
 
 def test_mvn_not_positive_definite(gp):
