@@ -265,6 +265,29 @@ def _single(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y) -> GPSLCObject:
 # src/estimation.jl
 # ------------------------------------------------------------------------------------------
 
+def likelihoodDistribution(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y, doT):
+    """likelihoodDistribution(...) -> (Y, CovWW, CovWWs, CovWWp, CovC11, CovC12, CovC21, CovC22)
+    (src/likelihood.jl:8-174; the method is chosen by which of U / X is None, like the reference's dispatch)."""
+    g = _single(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y)
+    n = g.getN()
+    ctx = g.ctx()
+    outs = [np.empty((n, n), order="F") for _ in range(7)]
+    st = ctx.lib.gpslc_likelihood_distribution(ctx.h, _p(g.U), _p(g.uyLS), _p(g.xyLS), float(tyLS), float(yScale),
+                                               float(yNoise), float(doT), *[_p(o) for o in outs])
+    ctx.check(st)
+    return (g.Y.copy(), *outs)
+
+
+def extractParameters(g: "GPSLCObject", posteriorSampleIdx: int):
+    """extractParameters(g, i) -> (uyLS, xyLS, tyLS, yNoise, yScale, U) (src/utils.jl:92-124); ``i`` is
+    1-based like the reference, counting the retained posterior samples."""
+    i = int(posteriorSampleIdx) - 1
+    if not 0 <= i < g.getNumPosteriorSamples():
+        raise IndexError("posterior sample index out of range")   # Julia: BoundsError
+    return (None if g.uyLS is None else g.uyLS[:, i].copy(), None if g.xyLS is None else g.xyLS[:, i].copy(),
+            float(g.tyLS[i]), float(g.yNoise[i]), float(g.yScale[i]), None if g.U is None else g.U[:, :, i].copy())
+
+
 def conditionalITE(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y, doT):
     """conditionalITE(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y, doT) -> MeanITE (n,), CovITE (n, n)
     (src/estimation.jl:36-50; no jitter, like the reference)."""

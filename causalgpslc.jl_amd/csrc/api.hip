@@ -936,6 +936,99 @@ int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* c
     });
 }
 
+int gpslc_likelihood_distribution(gpslc_ctx* c, const double* U, const double* uyLS, const double* xyLS,
+                                  double tyLS, double yScale, double yNoise, double doT, double* CovWW,
+                                  double* CovWWs, double* CovWWp, double* CovC11, double* CovC12,
+                                  double* CovC21, double* CovC22) {
+    const double ty = tyLS, ysc = yScale, yno = yNoise;
+    int rc = check_common(c, 1, U, uyLS, xyLS, &ty, &ysc, &yno);
+    if (rc) return rc;
+    return guarded(c, [&]() {
+        ensure_streams(c);
+        hipStream_t st = c->streams[0];
+        const int n = (int)c->n, nt = c->nt;
+        const long long nlow = (long long)nt * (nt + 1) / 2, nsq = (long long)nt * nt;
+        DevBuf bU, buy, bxy, bty, bys, byn, info, tiles, inv, part, rect, outb;
+        const double* dU = c->nU ? up(bU, U, (size_t)n * c->nU) : nullptr;
+        const double* duy = c->nU ? up(buy, uyLS, c->nU) : nullptr;
+        const double* dxy = c->nX ? up(bxy, xyLS, c->nX) : nullptr;
+        const double* dty = up(bty, &ty, 1);
+        const double* dys = up(bys, &ysc, 1);
+        const double* dyn = up(byn, &yno, 1);
+        SampleParams sp{dU, duy, dxy, dty, dys, dyn, (long long)n * c->nU};
+        info.alloc(sizeof(int));
+        HC(hipMemsetAsync(info.p, 0, sizeof(int), st));
+        tiles.alloc((size_t)nlow * GP_TSQ * 8);
+        inv.alloc((size_t)nt * GP_TSQ * 8);
+        rect.alloc((size_t)6 * nsq * GP_TSQ * 8);        // K, Ks, Ks', Kss, W1, W2
+        outb.alloc((size_t)n * n * 8);
+        double* rb = rect.as<double>();
+        const long long rs = nsq * GP_TSQ;
+        TRef Kt = rect_ref(rb, rs, nt), Kst = rect_ref(rb + rs, rs, nt), KsTt = rect_ref(rb + 2 * rs, rs, nt),
+             Ksst = rect_ref(rb + 3 * rs, rs, nt), W1 = rect_ref(rb + 4 * rs, rs, nt), W2 = rect_ref(rb + 5 * rs, rs, nt);
+        TRef M = lower_ref(tiles.as<double>(), nlow * GP_TSQ);
+        // A = K + yNoise I (lower tiles) and its factor
+        GramArgs ga{};
+        ga.X = c->dX; ga.T = c->dT; ga.p = sp; ga.s0 = 0; ga.n = n; ga.nX = c->nX; ga.nU = c->nU; ga.nt = nt;
+        ga.M = M; ga.part = nullptr; ga.with_sums = 0; ga.f32 = 0;
+        launch_gram(ga, 1, st);
+        potrf_tiles(c, M, nt, nt, inv.as<double>(), (long long)nt * GP_TSQ, info.as<int>(), 0, 1, st);
+        LdBuildArgs la{c->dX, c->dT, sp, 0, n, c->nX, c->nU, nt, doT, Kt, Kst, KsTt, Ksst};
+        launch_ld_build(la, st);
+        auto emit = [&](const TRef& R, double* host, double diag_add) {
+            if (!host) return;
+            launch_rect_gather(RectGatherArgs{R, n, nt, outb.as<double>(), diag_add}, st);
+            HC(hipStreamSynchronize(st));
+            HC(hipMemcpy(host, outb.p, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+        };
+        emit(Kt, CovWW, 0.0);
+        emit(Kst, CovWWs, 0.0);
+        emit(Kt, CovWWp, yno);
+        if (CovC11 || CovC12 || CovC21 || CovC22) {
+            // W1 = K L^-T, W2 = Ks' L^-T  (copies, then the tile-level left-looking solve)
+            HC(hipMemcpyAsync(W1.base, Kt.base, (size_t)rs * 8, hipMemcpyDeviceToDevice, st));
+            HC(hipMemcpyAsync(W2.base, KsTt.base, (size_t)rs * 8, hipMemcpyDeviceToDevice, st));
+            TRef invref = TRef{inv.as<double>(), (long long)nt * GP_TSQ, 1, 0, 0, 0};
+            for (TRef* Wp : {&W1, &W2}) {
+                for (int k = 0; k < nt; ++k) {
+                    if (k > 0) {
+                        GemmArgs g{};
+                        g.A = *Wp; g.B = M; g.C = *Wp;
+                        g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = nt; g.mj = 1;
+                        g.k0 = 0; g.k1 = k; g.accumulate = 1; g.nbatch = 1; g.ntiles = nt;
+                        gemm(c, g, st);
+                    }
+                    GemmArgs g{};
+                    g.A = *Wp; g.B = invref; g.C = *Wp;
+                    g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = nt; g.mj = 1;
+                    g.k0 = k; g.k1 = k + 1; g.accumulate = 0; g.nbatch = 1; g.ntiles = nt;
+                    gemm(c, g, st);
+                }
+            }
+            // C11 = K - W1 W1', C12 = Ks - W1 W2', C21 = Ks' - W2 W1', C22 = Kss - W2 W2'   (src/likelihood.jl:46-49)
+            auto block = [&](const TRef& Cm, const TRef& Wa, const TRef& Wb, double* host) {
+                if (!host) return;
+                GemmArgs g{};
+                g.A = Wa; g.B = Wb; g.C = Cm;
+                g.shape = 1; g.i0 = 0; g.j0 = 0; g.mi = nt; g.mj = nt;
+                g.k0 = 0; g.k1 = nt; g.accumulate = 1; g.nbatch = 1; g.ntiles = nt * nt;
+                gemm(c, g, st);
+                emit(Cm, host, 0.0);
+            };
+            block(Kt, W1, W1, CovC11);      // K, Ks, Ks', Kss are consumed in place: emitted above already
+            block(Kst, W1, W2, CovC12);
+            block(KsTt, W2, W1, CovC21);
+            block(Ksst, W2, W2, CovC22);
+        }
+        HC(hipStreamSynchronize(st));
+        HC(hipGetLastError());
+        int hinfo = 0;
+        HC(hipMemcpy(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost));
+        c->last_info.assign(1, hinfo);
+        return hinfo;
+    });
+}
+
 int gpslc_sate_samples(const double* meanSATE, const double* varSATE, int64_t S, int32_t spp, uint64_t seed,
                        const double* z, double* out) {
     if (!meanSATE) return -1;

@@ -145,3 +145,13 @@ struct QuadRowsArgs { TRef M; int n, nt, naug; long long S; double* logdet; doub
 struct RowNormArgs { TRef W; int nt, naug; long long S; double* quad; };   // quad[q] = ||row q of W||^2
 void launch_row_norms(const RowNormArgs& a, hipStream_t st);
 void launch_quad_rows(const QuadRowsArgs& a, hipStream_t st);
+
+// likelihoodDistribution (src/likelihood.jl:8-174): dense blocks as rectangular tile matrices
+struct LdBuildArgs {
+    const double* X; const double* T; SampleParams p; long long s0;
+    int n, nX, nU, nt; double doT;
+    TRef K, Ks, KsT, Kss;   // nt x nt rectangular each: CovWW, CovWWs, CovWWs', CovWsWs
+};
+void launch_ld_build(const LdBuildArgs& a, hipStream_t st);
+struct RectGatherArgs { TRef R; int n, nt; double* out; double diag_add; };   // -> column-major n x n
+void launch_rect_gather(const RectGatherArgs& a, hipStream_t st);

@@ -414,3 +414,86 @@ __global__ __launch_bounds__(256) void draws_kernel(DrawArgs a) {
 void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st) {
     hipLaunchKernelGGL(draws_kernel, dim3(a.nt, nbatch), dim3(256), 0, st, a);
 }
+
+// ---------------------------------------------------------------------------------------
+// likelihoodDistribution blocks (src/likelihood.jl:24-39): K = B.*E, Ks = diag(r) B, Ks' = B diag(r), Kss = B
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ld_build_kernel(LdBuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int F = a.nU + a.nX;
+    double* fr = sm;
+    double* fc = fr + F * GP_TS;
+    double* tr = fc + F * GP_TS;
+    double* tc = tr + GP_TS;
+    double* rr_ = tc + GP_TS;
+    double* rc_ = rr_ + GP_TS;
+    const int tid = threadIdx.x;
+    const int ti = blockIdx.x / a.nt, tj = blockIdx.x % a.nt;
+    const long long s = a.s0;
+    const int n = a.n;
+    const int gi0 = ti * GP_TS, gj0 = tj * GP_TS;
+    const double tl = a.p.tyLS[s];
+    const double wt = 1.0 / (tl * tl);
+    for (int idx = tid; idx < F * GP_TS; idx += 256) {
+        const int f = idx >> 7, r = idx & 127;
+        const double* src = (f < a.nU) ? a.p.U + s * a.p.u_sstride + (long long)f * n
+                                       : a.X + (long long)(f - a.nU) * n;
+        const double il = 1.0 / ((f < a.nU) ? a.p.uyLS[s * a.nU + f] : a.p.xyLS[s * a.nX + (f - a.nU)]);
+        fr[idx] = (gi0 + r < n) ? src[gi0 + r] * il : 0.0;
+        fc[idx] = (gj0 + r < n) ? src[gj0 + r] * il : 0.0;
+    }
+    if (tid < GP_TS) {
+        const double t1 = (gi0 + tid < n) ? a.T[gi0 + tid] : 0.0;
+        const double t2 = (gj0 + tid < n) ? a.T[gj0 + tid] : 0.0;
+        tr[tid] = t1; tc[tid] = t2;
+        const double d1 = t1 - a.doT, d2 = t2 - a.doT;
+        rr_[tid] = gp_exp_neg(-((d1 * d1) * wt));
+        rc_[tid] = gp_exp_neg(-((d2 * d2) * wt));
+    }
+    __syncthreads();
+    const double ys = a.p.yScale[s];
+    double* tK = tref_tile(a.K, 0, ti, tj);
+    double* tKs = tref_tile(a.Ks, 0, ti, tj);
+    double* tKsT = tref_tile(a.KsT, 0, ti, tj);
+    double* tKss = tref_tile(a.Kss, 0, ti, tj);
+    for (int idx = tid; idx < GP_TSQ; idx += 256) {
+        const int c = idx >> 7, r = idx & 127;
+        double lux = 0.0;
+        for (int f = 0; f < F; ++f) {
+            const double d = fr[f * GP_TS + r] - fc[f * GP_TS + c];
+            lux = fma(d, d, lux);
+        }
+        const double dt = tr[r] - tc[c];
+        double Bv = ys * gp_exp_neg(-lux);
+        double Ev = gp_exp_neg(-((dt * dt) * wt));
+        if (gi0 + r >= n || gj0 + c >= n) { Bv = 0.0; Ev = 0.0; }
+        tK[idx] = Bv * Ev;
+        tKs[idx] = rr_[r] * Bv;
+        tKsT[idx] = Bv * rc_[c];
+        tKss[idx] = Bv;
+    }
+}
+void launch_ld_build(const LdBuildArgs& a, hipStream_t st) {
+    const int F = a.nU + a.nX;
+    const int bytes = (2 * F * GP_TS + 4 * GP_TS) * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ld_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (2 * MAXF * GP_TS + 4 * GP_TS) * 8);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ld_build_kernel, dim3(a.nt * a.nt), dim3(256), bytes, st, a);
+}
+
+__global__ __launch_bounds__(256) void rect_gather_kernel(RectGatherArgs a) {
+    const int ti = blockIdx.x / a.nt, tj = blockIdx.x % a.nt;
+    const double* t = tref_tile(a.R, 0, ti, tj);
+    for (int idx = threadIdx.x; idx < GP_TSQ; idx += 256) {
+        const int c = idx >> 7, r = idx & 127;
+        const long long gi = (long long)ti * GP_TS + r, gj = (long long)tj * GP_TS + c;
+        if (gi < a.n && gj < a.n) a.out[gi + (long long)a.n * gj] = t[idx] + (gi == gj ? a.diag_add : 0.0);
+    }
+}
+void launch_rect_gather(const RectGatherArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(rect_gather_kernel, dim3(a.nt * a.nt), dim3(256), 0, st, a);
+}

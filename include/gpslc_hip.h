@@ -147,6 +147,15 @@ int gpslc_ite_distributions(gpslc_ctx* ctx, int64_t S, const double* U, const do
                             const double* yNoise, double doT, double pred_noise,
                             double* MeanITEs, double* CovITEs);
 
+/* likelihoodDistribution(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y, doT) (src/likelihood.jl:8-52 and
+ * its three reduced methods :55-94, :97-136, :139-174) for ONE parameter set, as the reference exports it:
+ * the dense n x n blocks CovWW, CovWWs, CovWWp and the four posterior blocks CovC11..CovC22 (:46-49),
+ * column-major; any output may be NULL.  (Y, the first element of the reference's tuple, is the caller's.) */
+int gpslc_likelihood_distribution(gpslc_ctx* ctx, const double* U, const double* uyLS, const double* xyLS,
+                                  double tyLS, double yScale, double yNoise, double doT, double* CovWW,
+                                  double* CovWWs, double* CovWWp, double* CovC11, double* CovC12,
+                                  double* CovC21, double* CovC22);
+
 /* SATEsamples (src/estimation.jl:148-163): out[j*spp + d] = mean[j] + var[j] * z — the variance
  * is used as the standard deviation, as the reference does (src/estimation.jl:159).  Host-only
  * arithmetic; z_or_null (S*spp) or Philox stream `seed`, stream id 2^40 + j. */

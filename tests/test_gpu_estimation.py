@@ -287,3 +287,36 @@ def test_c_abi_argument_errors(gp):
     # S = 0 is a no-op
     assert lib.gpslc_predict(ctx.h, 0, None, None, None, None, None, None, 1, p(one), 1e-10, 0, 0, None,
                              None, None, None, None) == 0
+
+
+@pytest.mark.parametrize("n,shape,bt", [(1, "UX", False), (24, "UX", False), (150, "U", True), (200, "X", False),
+                                         (140, "T", True)])
+def test_likelihood_distribution_blocks(gp, n, shape, bt):
+    """The reference's exported helper (src/likelihood.jl:8-174): all 8 outputs against the literal oracle."""
+    c = cases.make_case(n, shape, bt, S=1, seed=60 + n)
+    p = cases.samples_of(c)[0]
+    doT = c["doTs"][1]
+    ref = orc.likelihood_distribution(p.uyLS, p.xyLS, p.tyLS, p.yNoise, p.yScale, p.U, c["X"], c["T"], c["Y"], doT)
+    out = gp.likelihoodDistribution(p.uyLS, p.xyLS, p.tyLS, p.yNoise, p.yScale, p.U, c["X"], c["T"], c["Y"], doT)
+    assert len(out) == 8
+    assert np.array_equal(out[0], ref[0])
+    names = ["Y", "CovWW", "CovWWs", "CovWWp", "CovC11", "CovC12", "CovC21", "CovC22"]
+    for k in range(1, 8):
+        assert out[k].shape == (n, n)
+        assert np.max(np.abs(out[k] - ref[k])) <= 1e-9 * p.yScale, names[k]
+    # conditionalITE's combination of the blocks (src/estimation.jl:47)
+    cov = out[4] - out[5] - out[6] + out[7]
+    _, cref = orc.conditional_ite(p.uyLS, p.xyLS, p.tyLS, p.yNoise, p.yScale, p.U, c["X"], c["T"], c["Y"], doT)
+    assert np.max(np.abs(cov - cref)) <= 1e-9 * p.yScale
+
+
+def test_extract_parameters_accessor(gp):
+    c = cases.make_case(12, "UX", False, S=3, seed=2)
+    g = cases.gpslc_object(gp, c)
+    uyLS, xyLS, tyLS, yNoise, yScale, U = gp.extractParameters(g, 2)     # 1-based, src/utils.jl:92-124
+    assert np.array_equal(uyLS, c["uyLS"][:, 1]) and np.array_equal(xyLS, c["xyLS"][:, 1])
+    assert (tyLS, yNoise, yScale) == (c["tyLS"][1], c["yNoise"][1], c["yScale"][1])
+    assert np.array_equal(U, c["U"][:, :, 1]) and U.shape == (12, gp.getNU(g))
+    assert gp.getNumPosteriorSamples(g) == 3 and gp.getN(g) == 12 and gp.getNX(g) == 3
+    with pytest.raises(IndexError):
+        gp.extractParameters(g, 4)
