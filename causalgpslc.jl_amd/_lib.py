@@ -66,6 +66,8 @@ SIGNATURES = {
                                           C.c_double, _D, _D]),
     "gpslc_likelihood_distribution": (C.c_int, [C.c_void_p, _D, _D, _D, C.c_double, C.c_double, C.c_double,
                                                 C.c_double, _D, _D, _D, _D, _D, _D, _D]),
+    "gpslc_summarize": (C.c_int, [C.c_void_p, _D, C.c_int64, C.c_int64, C.c_double, _D, _D, _D]),
+    "gpslc_summarize_dev": (C.c_int, [C.c_void_p, _D, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, _D, _D, _D]),
     "gpslc_sate_samples": (C.c_int, [_D, _D, C.c_int64, C.c_int32, C.c_uint64, _D, _D]),
     "gpslc_last_info": (C.c_int, [C.c_void_p, c_int32_p, C.c_int64]),
     "gpslc_profile_reset": (C.c_int, [C.c_void_p]),

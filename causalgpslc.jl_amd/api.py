@@ -421,14 +421,15 @@ def predictCounterfactualEffects(g: GPSLCObject, nSamplesPerMixture, fidelity=10
 
 
 def summarizeEstimates(samples, credible_interval=0.90):
-    """Mean and credible bounds per individual (src/driver.jl:129-149; Julia's type-7 quantile).
-    Host-side: O(n*m) glue, listed as 'next-4' in SURVEY.md §8f."""
-    lo = (1 - credible_interval) / 2
-    hi = 1 - lo
-    s = np.asarray(samples, dtype=np.float64)
-    return {"Individual": np.arange(1, s.shape[0] + 1), "Mean": s.mean(axis=1),
-            "LowerBound": np.quantile(s, lo, axis=1, method="linear"),
-            "UpperBound": np.quantile(s, hi, axis=1, method="linear")}
+    """summarizeEstimates(samples; credible_interval=0.90) (src/driver.jl:129-149): Individual, Mean,
+    LowerBound, UpperBound per row of the n x m sample matrix, computed on the GPU (in-LDS sort per individual,
+    Julia's type-7 quantile).  Rows longer than 16384 samples are not supported yet."""
+    s = _f(np.atleast_2d(samples))
+    n, m = s.shape
+    mean, lo, hi = np.empty(n), np.empty(n), np.empty(n)
+    ctx = _kernel_ctx()
+    ctx.check(ctx.lib.gpslc_summarize(ctx.h, _p(s), n, m, float(credible_interval), _p(mean), _p(lo), _p(hi)))
+    return {"Individual": np.arange(1, n + 1), "Mean": mean, "LowerBound": lo, "UpperBound": hi}
 
 
 # ------------------------------------------------------------------------------------------

@@ -1029,6 +1029,52 @@ int gpslc_likelihood_distribution(gpslc_ctx* c, const double* U, const double* u
     });
 }
 
+static int summarize_impl(gpslc_ctx* c, const double* dx, int64_t n, int64_t m, int64_t rs, int64_t cs,
+                          double ci, double* dmean, double* dlo, double* dhi) {
+    ensure_streams(c);
+    int mpad = 1;
+    while (mpad < m) mpad <<= 1;
+    const double lowerQ = (1.0 - ci) / 2.0;          // src/driver.jl:130-131
+    const double upperQ = 1.0 - lowerQ;
+    launch_summarize(SummArgs{dx, rs, cs, (int)n, (int)m, mpad, lowerQ, upperQ, dmean, dlo, dhi}, c->streams[0]);
+    HC(hipStreamSynchronize(c->streams[0]));
+    HC(hipGetLastError());
+    return GPSLC_OK;
+}
+
+int gpslc_summarize_dev(gpslc_ctx* c, const double* samples, int64_t n, int64_t m, int64_t row_stride,
+                        int64_t col_stride, double credible_interval, double* mean, double* lower, double* upper) {
+    if (!c) return -1;
+    if (!samples) return bad_arg(c, 2, "samples is NULL");
+    if (n < 1) return bad_arg(c, 3, "n < 1");
+    if (m < 1 || m > 16384) return bad_arg(c, 4, "m must be in 1..16384 (one LDS-resident row per workgroup)");
+    if (!(credible_interval > 0.0 && credible_interval < 1.0)) return bad_arg(c, 7, "credible_interval not in (0,1)");
+    if (!mean || !lower || !upper) return bad_arg(c, 8, "output is NULL");
+    return guarded(c, [&]() { return summarize_impl(c, samples, n, m, row_stride, col_stride, credible_interval,
+                                                    mean, lower, upper); });
+}
+
+int gpslc_summarize(gpslc_ctx* c, const double* samples, int64_t n, int64_t m, double credible_interval,
+                    double* mean, double* lower, double* upper) {
+    if (!c) return -1;
+    if (!samples) return bad_arg(c, 2, "samples is NULL");
+    if (n < 1) return bad_arg(c, 3, "n < 1");
+    if (m < 1 || m > 16384) return bad_arg(c, 4, "m must be in 1..16384 (one LDS-resident row per workgroup)");
+    if (!(credible_interval > 0.0 && credible_interval < 1.0)) return bad_arg(c, 5, "credible_interval not in (0,1)");
+    if (!mean || !lower || !upper) return bad_arg(c, 6, "output is NULL");
+    return guarded(c, [&]() {
+        DevBuf bx, o;
+        const double* dx = up(bx, samples, (size_t)n * m);
+        o.alloc(sizeof(double) * 3 * n);
+        double* d = o.as<double>();
+        summarize_impl(c, dx, n, m, 1, n, credible_interval, d, d + n, d + 2 * n);
+        HC(hipMemcpy(mean, d, sizeof(double) * n, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(lower, d + n, sizeof(double) * n, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(upper, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+        return GPSLC_OK;
+    });
+}
+
 int gpslc_sate_samples(const double* meanSATE, const double* varSATE, int64_t S, int32_t spp, uint64_t seed,
                        const double* z, double* out) {
     if (!meanSATE) return -1;

@@ -155,3 +155,11 @@ struct LdBuildArgs {
 void launch_ld_build(const LdBuildArgs& a, hipStream_t st);
 struct RectGatherArgs { TRef R; int n, nt; double* out; double diag_add; };   // -> column-major n x n
 void launch_rect_gather(const RectGatherArgs& a, hipStream_t st);
+
+// summarizeEstimates (src/driver.jl:129-149): per-row mean and two type-7 quantiles of an n x m sample matrix
+struct SummArgs {
+    const double* x; long long rs, cs;   // sample (i, j) at x[i*rs + j*cs]
+    int n, m, mpad; double lowerQ, upperQ;
+    double* mean; double* lower; double* upper;
+};
+void launch_summarize(const SummArgs& a, hipStream_t st);

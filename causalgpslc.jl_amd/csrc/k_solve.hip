@@ -497,3 +497,65 @@ __global__ __launch_bounds__(256) void rect_gather_kernel(RectGatherArgs a) {
 void launch_rect_gather(const RectGatherArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(rect_gather_kernel, dim3(a.nt * a.nt), dim3(256), 0, st, a);
 }
+
+// ---------------------------------------------------------------------------------------
+// summarizeEstimates: one workgroup per individual.  The row is gathered into LDS (padded with +inf to a
+// power of two), sorted with a bitonic network, and the two order statistics are interpolated exactly as
+// Julia's Statistics.quantile does (type 7: aleph = m p + (1 - p), j = trunc(aleph), a + gamma (b - a)).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double julia_quantile_sorted(const double* v, int m, double p) {
+#pragma clang fp contract(off)   // Julia evaluates these expressions without fused multiply-adds
+    if (m == 1) return v[0];
+    const double aleph = (double)m * p + (1.0 - p);
+    int j = (int)aleph;                       // trunc
+    j = min(max(j, 1), m - 1);
+    double gam = aleph - (double)j;
+    gam = fmin(fmax(gam, 0.0), 1.0);
+    const double a = v[j - 1], b = v[j];
+    return a + gam * (b - a);
+}
+
+__global__ __launch_bounds__(256) void summarize_kernel(SummArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double v[];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const long long i = blockIdx.x;
+    double acc = 0.0;
+    for (int j = tid; j < a.mpad; j += 256) {
+        double x = INFINITY;
+        if (j < a.m) { x = a.x[i * a.rs + (long long)j * a.cs]; acc += x; }
+        v[j] = x;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    const double total = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int k = 2; k <= a.mpad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < a.mpad; t += 256) {
+                const int u = t ^ j;
+                if (u > t) {
+                    const bool up = (t & k) == 0;
+                    const double p = v[t], q = v[u];
+                    if ((p > q) == up) { v[t] = q; v[u] = p; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        a.mean[i] = total / (double)a.m;
+        a.lower[i] = julia_quantile_sorted(v, a.m, a.lowerQ);
+        a.upper[i] = julia_quantile_sorted(v, a.m, a.upperQ);
+    }
+}
+void launch_summarize(const SummArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)summarize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  16384 * 8);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(summarize_kernel, dim3(a.n), dim3(256), (size_t)a.mpad * 8, st, a);
+}

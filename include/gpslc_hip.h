@@ -162,6 +162,17 @@ int gpslc_likelihood_distribution(gpslc_ctx* ctx, const double* U, const double*
 int gpslc_sate_samples(const double* meanSATE, const double* varSATE, int64_t S, int32_t spp,
                        uint64_t seed, const double* z_or_null, double* out /* S*spp */);
 
+/* summarizeEstimates(samples; credible_interval) (src/driver.jl:129-149): per-individual Mean and the
+ * (1-ci)/2 and 1-(1-ci)/2 quantiles (Julia's Statistics.quantile, type 7) of an n x m sample matrix
+ * (column-major, samples[i + n*j]); m <= 16384.  The _dev variant reads device memory with explicit strides
+ * (sample (i, j) at samples[i*row_stride + j*col_stride]) so that level l of gpslc_predict_dev's ite_draws
+ * (L x n x M, level fastest) is summarised in place with samples = draws + l, row_stride = L,
+ * col_stride = L*n, and writes device outputs: the draw tensor never leaves HBM. */
+int gpslc_summarize(gpslc_ctx* ctx, const double* samples, int64_t n, int64_t m, double credible_interval,
+                    double* mean, double* lower, double* upper);
+int gpslc_summarize_dev(gpslc_ctx* ctx, const double* samples, int64_t n, int64_t m, int64_t row_stride,
+                        int64_t col_stride, double credible_interval, double* mean, double* lower, double* upper);
+
 /* 1-based failing pivot (0 = ok) of every posterior sample of the last predict / y_logpdf /
  * ite_distributions call; codes > n refer to the CovITE factorisation (pivot - n). */
 int gpslc_last_info(const gpslc_ctx* ctx, int32_t* info, int64_t S);

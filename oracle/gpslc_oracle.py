@@ -324,14 +324,27 @@ def predict_counterfactual_effects(samples, X, T, Y, spp, z, fidelity=100,
     return ite, rng
 
 
+def julia_quantile(v, p):
+    """Statistics.quantile(v, p) of Julia 1.7 (type 7, alpha = beta = 1): sort, aleph = n p + (1 - p),
+    j = clamp(trunc(aleph), 1, n-1), gamma = clamp(aleph - j, 0, 1), v[j] + gamma (v[j+1] - v[j])."""
+    v = np.sort(np.asarray(v, dtype=np.float64))
+    n = v.shape[0]
+    if n == 1:
+        return float(v[0])
+    aleph = n * p + (1.0 - p)
+    j = min(max(int(aleph), 1), n - 1)
+    gam = min(max(aleph - j, 0.0), 1.0)
+    return float(v[j - 1] + gam * (v[j] - v[j - 1]))
+
+
 def summarize_estimates(samples, credible_interval=0.90):
-    """src/driver.jl:129-149 (Julia ``quantile`` = type 7 = numpy 'linear')."""
+    """src/driver.jl:129-149: mean(samples, dims=2) and the two quantiles per individual."""
     lo = (1 - credible_interval) / 2
     hi = 1 - lo
     samples = np.asarray(samples, dtype=np.float64)
     return (samples.mean(axis=1),
-            np.quantile(samples, lo, axis=1, method="linear"),
-            np.quantile(samples, hi, axis=1, method="linear"))
+            np.array([julia_quantile(r, lo) for r in samples]),
+            np.array([julia_quantile(r, hi) for r in samples]))
 
 
 # ----------------------------------------------------------------------------

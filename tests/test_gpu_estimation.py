@@ -320,3 +320,23 @@ def test_extract_parameters_accessor(gp):
     assert gp.getNumPosteriorSamples(g) == 3 and gp.getN(g) == 12 and gp.getNX(g) == 3
     with pytest.raises(IndexError):
         gp.extractParameters(g, 4)
+
+
+def test_summarize_estimates_on_device(gp):
+    """src/driver.jl:129-149; test/driver.jl:54-70 known answers (0:100 -> 5/95 and 10/90) and random rows
+    against the oracle's restatement of Julia's type-7 quantile (bit-exact: sorting and one interpolation)."""
+    s = np.arange(101, dtype=float)[None, :]
+    out = gp.summarizeEstimates(s, credible_interval=0.9)
+    assert np.isclose(out["LowerBound"][0], 5.0) and np.isclose(out["UpperBound"][0], 95.0) and out["Mean"][0] == 50.0
+    out = gp.summarizeEstimates(s, credible_interval=0.8)
+    assert np.isclose(out["LowerBound"][0], 10.0) and np.isclose(out["UpperBound"][0], 90.0)
+    rng = np.random.default_rng(0)
+    for (n, m) in [(1, 1), (3, 2), (150, 150), (37, 1000), (5, 5000), (2, 16384)]:
+        x = rng.standard_normal((n, m)) * rng.uniform(0.1, 10, (n, 1))
+        out = gp.summarizeEstimates(x, credible_interval=0.9)
+        mean, lo, hi = orc.summarize_estimates(x, 0.9)
+        assert np.array_equal(out["LowerBound"], lo) and np.array_equal(out["UpperBound"], hi), (n, m)
+        assert np.allclose(out["Mean"], mean, rtol=1e-14, atol=1e-16)
+        assert np.array_equal(out["Individual"], np.arange(1, n + 1))
+    with pytest.raises(gp.GPSLCError):
+        gp.summarizeEstimates(np.zeros((2, 20000)))

@@ -99,6 +99,14 @@ def test_summarize_estimates_quantiles():  # test/driver.jl:54-70
     assert np.isclose(lo[0], 10.0) and np.isclose(hi[0], 90.0)
 
 
+def test_julia_quantile_matches_numpy_linear():
+    rng = np.random.default_rng(1)
+    for m in (2, 7, 150, 1001):
+        v = rng.standard_normal(m)
+        for p in (0.05, 0.1, 0.5, 0.95):
+            assert np.isclose(orc.julia_quantile(v, p), np.quantile(v, p, method="linear"), rtol=1e-14, atol=1e-15)
+
+
 def test_sate_samples_uses_variance_as_sigma():  # src/estimation.jl:159
     out = orc.sate_samples(np.array([1.0, 2.0]), np.array([0.25, 4.0]), 2, np.array([1.0, -1.0, 0.5, 2.0]))
     assert np.allclose(out, [1.25, 0.75, 4.0, 10.0])
