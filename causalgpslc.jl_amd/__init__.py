@@ -12,6 +12,7 @@ from .api import (  # noqa: F401
     summarizeEstimates, yLogpdf, gpLogpdf, mvnLogpdf, predict, doTRange, getN, getNX, getNU, getNumPosteriorSamples,
 )
 from . import synth  # noqa: F401
+from .pack import saveGPSLCObject, loadGPSLCObject  # noqa: F401
 from .inference import (  # noqa: F401
     gpslc, Posterior, prepareData, generateSigmaU, removeAdjacent, getPriorParameters, getHyperParameters,
     toMatrixModel,
