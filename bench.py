@@ -131,7 +131,8 @@ def main():
     def step():
         st = ctx.lib.gpslc_predict_dev(ctx.h, Sr, ptr(dU), ptr(duy), ptr(dxy), ptr(dty), ptr(dys), ptr(dyn), L,
                                        ptr(ddo), 1e-10, 0, 0, None, ptr(mS), ptr(vS), ptr(mI), None)
-        ctx.check(st)
+        if not (st > 0 and os.environ.get("GPSLC_GEMM_DIAG")):   # diagnostic kernels produce garbage (non-PD)
+            ctx.check(st)
         if world > 1:   # the single end-of-step collective: SATE summaries of every rank's shard
             if rehearsal:   # gloo: gather through host memory
                 gm = [torch.empty(Sr * L, dtype=torch.float64) for _ in range(world)]
@@ -167,8 +168,9 @@ def main():
         val = total_samples / dt
         # sanity: results are finite and the two SATE paths agree (mean of MeanITE == MeanSATE)
         ms_h = mS.cpu().numpy()
-        assert np.all(np.isfinite(ms_h)), "non-finite SATE in the benchmark output"
-        if mI is not None:
+        diag = bool(os.environ.get("GPSLC_GEMM_DIAG"))   # timing-only diagnostic kernels: results are garbage
+        assert diag or np.all(np.isfinite(ms_h)), "non-finite SATE in the benchmark output"
+        if mI is not None and not diag:
             mi_h = mI.cpu().numpy().reshape(n, Sr, L, order="F")
             chk = np.max(np.abs(mi_h.mean(axis=0)[:, 0] - ms_h.reshape(Sr, L, order="F")[:, 0]))
             assert chk <= (1e-5 if a.fp32_kernel else 1e-8) * max(1.0, np.max(np.abs(ms_h))), chk

@@ -124,6 +124,8 @@ void ensure_streams(gpslc_ctx* c) {
 // ---- profiled launch of the accumulate-mode tile kernel ---------------------------------
 void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
+    static const int diag_skip = getenv("GPSLC_GEMM_DIAG") ? atoi(getenv("GPSLC_GEMM_DIAG")) : 0;
+    g.diag_skip = diag_skip;   // timing-only diagnostic, results are garbage when set
     static const int dbg_m = getenv("GPSLC_GEMM_DBG") ? atoi(getenv("GPSLC_GEMM_DBG")) : 0;
     static bool dbg_done = false;
     unsigned long long* dbg_buf = nullptr;

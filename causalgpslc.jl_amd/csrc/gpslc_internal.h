@@ -43,6 +43,7 @@ struct GemmArgs {
     int short_row0;   // output tile rows >= short_row0 (augmented right-hand-side rows) carry only
     int short_rows;   // `short_rows` live rows: dead 16-row sub-tiles are skipped (0 = feature off)
     const unsigned short* order;  // optional (ii, jj) pairs: output-tile visiting order (L2-blocked), or null
+    int diag_skip;                // DIAGNOSTIC ONLY (GPSLC_GEMM_DIAG): 1 = skip in-loop global loads, 2 = also LDS writes
     unsigned long long* dbg;      // diagnostic builds only: per-workgroup s_memtime stamps, or null
 };
 

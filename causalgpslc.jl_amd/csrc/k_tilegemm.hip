@@ -48,7 +48,7 @@ __device__ __forceinline__ d4 mfma_step(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, NEG);
 }
 
-template <int ACC>
+template <int ACC, int DIAG>
 __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
@@ -180,15 +180,26 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
             // unrolled by two, the staging sets swapping roles: set A holds slab s+1 while slab s+2
             // streams into set B.  The barrier that ends the last slab also protects the LDS buffers
             // against the next work item's first lstore.
-            for (int s = 0; s < nslab; s += 2) {
-                if (s + 2 < nslab) gload(s + 2, ra2, rb2);
-                compute(0, s);
-                lstore(1, ra, rb);
-                __syncthreads();
-                if (s + 3 < nslab) gload(s + 3, ra, rb);
-                compute(1, s + 1);
-                if (s + 2 < nslab) lstore(0, ra2, rb2);
-                __syncthreads();
+            if (DIAG == 0) {
+                for (int s = 0; s < nslab; s += 2) {
+                    if (s + 2 < nslab) gload(s + 2, ra2, rb2);
+                    compute(0, s);
+                    lstore(1, ra, rb);
+                    __syncthreads();
+                    if (s + 3 < nslab) gload(s + 3, ra, rb);
+                    compute(1, s + 1);
+                    if (s + 2 < nslab) lstore(0, ra2, rb2);
+                    __syncthreads();
+                }
+            } else {   // timing-only diagnostic: same MFMA / ds_read stream, operand traffic removed
+                for (int s = 0; s < nslab; s += 2) {
+                    compute(0, s);
+                    if (DIAG == 1) lstore(1, ra, rb);
+                    __syncthreads();
+                    compute(1, s + 1);
+                    if (DIAG == 1) lstore(0, ra, rb);
+                    __syncthreads();
+                }
             }
         }
         if (g.dbg) st2 = __builtin_amdgcn_s_memtime();
@@ -220,23 +231,33 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
     }
 }
 
+template <int ACC, int DIAG>
+static void launch_one(const GemmArgs& g, unsigned grid, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)tile_gemm_nt_kernel<ACC, DIAG>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((tile_gemm_nt_kernel<ACC, DIAG>), dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
+}
+
 void launch_tile_gemm(const GemmArgs& g, hipStream_t st) {
     if (g.ntiles <= 0 || g.nbatch <= 0) return;
     static int slots = 0;
     if (slots == 0) {
-        (void)hipFuncSetAttribute((const void*)tile_gemm_nt_kernel<1>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)tile_gemm_nt_kernel<0>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        slots = 2 * cus;   // 2 workgroups per CU (196+ VGPRs, 72 KiB LDS each)
+        slots = 2 * cus;   // 2 workgroups per CU (227 VGPRs, 72 KiB LDS each)
     }
     const long long W = (long long)g.ntiles * g.nbatch;
     const unsigned grid = (unsigned)(W < slots ? W : slots);
-    if (g.accumulate)
-        hipLaunchKernelGGL(tile_gemm_nt_kernel<1>, dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
-    else
-        hipLaunchKernelGGL(tile_gemm_nt_kernel<0>, dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
+    if (g.diag_skip == 1) {        // timing-only diagnostics (GPSLC_GEMM_DIAG), separate instantiations
+        if (g.accumulate) launch_one<1, 1>(g, grid, st); else launch_one<0, 1>(g, grid, st);
+    } else if (g.diag_skip == 2) {
+        if (g.accumulate) launch_one<1, 2>(g, grid, st); else launch_one<0, 2>(g, grid, st);
+    } else {
+        if (g.accumulate) launch_one<1, 0>(g, grid, st); else launch_one<0, 0>(g, grid, st);
+    }
 }
