@@ -11,10 +11,11 @@ process group).  Posterior samples shard over ranks with no data-path collective
 the (S x L) SATE arrays closes each step (weak scaling: per-GPU work is fixed).
 
 The JSON line carries
-  roofline      the dominant kernel (tile_gemm_nt_kernel<1>, the f64-MFMA tile update): algorithmic
-                flop / HIP-event time of every launch inside the timed region, against the fp64 matrix
-                peak (78.6 TFLOP/s, AMD spec; the guides list no f64 MFMA rate — see DESIGN.md for the
-                measured micro-benchmark rate);
+  roofline      the dominant kernel (tile_gemm_nt_kernel<1, 0>, the f64-MFMA tile update): algorithmic
+                flop (textbook count: diagonal tiles half, augmented rows by their live rows) / HIP-event
+                time of every launch inside the timed region, against the fp64 matrix peak (78.6 TFLOP/s,
+                AMD spec; the guides list no f64 MFMA rate — DESIGN.md §4 has the measured micro-benchmark:
+                76 TFLOP/s register-only); `traffic` = HBM bytes per launch from the committed PMC passes;
   cpu_baseline  the literal CPU restatement of the reference algorithm (oracle/, NumPy/OpenBLAS) timed
                 on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
