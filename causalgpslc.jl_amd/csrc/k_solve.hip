@@ -179,6 +179,185 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// MeanITE for many intervention levels on the MFMA (L > 4, fp64):
+//   MeanITE[i, l] = sum_j B_ij (r_j(l) alpha_j)  -  sum_j (B_ij e_ij) alpha_j
+// = (B R)[i, l] - (K alpha)[i],  R[j, l] = r_j(l) alpha_j  — a (128 x N)(N x 64) product per row block.
+// No operand tile goes through LDS: the f64 16x16x4 MFMA wants one element per lane, and each lane
+// computes exactly its own B_rc (row = 16m + lane&15, column = 4kk + lane>>4) and K_rc = B_rc e_rc from
+// the staged features; R is staged per 64-column chunk.  The K alpha term runs as a second MFMA product
+// with the same k order: when doT == T for every instance r == e == 1, B and K, R[:, l] and alpha are
+// bit-identical, so both MFMA chains produce identical sums and the difference is exactly 0.0
+// (test/estimation.jl:6-66).
+// One workgroup = 128 rows x up to 64 levels; wave w owns rows 32w..32w+31 (2 row sub-tiles x 4 level
+// sub-tiles = 8 accumulators + 2 for K alpha).
+// ---------------------------------------------------------------------------------------
+typedef double d4s __attribute__((ext_vector_type(4)));
+#define IM_CC 64          // columns per staged chunk
+#define IM_RLD 80         // padded row of the R chunk (doubles): conflict-free ds_read_b64 across k rows
+#define IM_NL 64          // levels per pass
+
+template <int FREG>   // FREG > 0: this lane's two rows' features live in registers (F <= FREG); 0: read from LDS
+__global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int F = a.nU + a.nX;
+    double* fr = sm;                         // [F][128] row features / LS
+    const int FSL = FREG > F ? FREG : F;
+    double* fc = fr + F * GP_TS;             // [max(F, FREG)][IM_CC] column features / LS
+    double* trs = fc + FSL * IM_CC;          // [128]
+    double* tcs = trs + GP_TS;               // [IM_CC]
+    double* al = tcs + IM_CC;                // [IM_CC]
+    double* R = al + IM_CC;                  // [IM_CC][IM_RLD]  r_j(l) * alpha_j
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int ib = blockIdx.x;
+    const long long b = blockIdx.y, s = a.s0 + b;
+    const int n = a.n, Np = a.nt * GP_TS;
+
+    auto feat_src = [&](int f) -> const double* {
+        return (f < a.nU) ? a.p.U + s * a.p.u_sstride + (long long)f * n : a.X + (long long)(f - a.nU) * n;
+    };
+    auto feat_il = [&](int f) -> double {
+        return 1.0 / ((f < a.nU) ? a.p.uyLS[s * a.nU + f] : a.p.xyLS[s * a.nX + (f - a.nU)]);
+    };
+    for (int idx = tid; idx < F * GP_TS; idx += 256) {
+        const int f = idx >> 7, rr = idx & 127;
+        const int g = ib * GP_TS + rr;
+        fr[idx] = (g < n) ? feat_src(f)[g] * feat_il(f) : 0.0;
+    }
+    if (tid < GP_TS) {
+        const int g = ib * GP_TS + tid;
+        trs[tid] = (g < n) ? a.T[g] : 0.0;
+    }
+    const double ys = a.p.yScale[s];
+    const double tl = a.p.tyLS[s];
+    const double wt = 1.0 / (tl * tl);
+    const double* alpha = a.alpha + b * Np;
+    const int r0 = 32 * wave + li;           // this lane's rows: r0 and r0 + 16
+    __syncthreads();
+    double af0[FREG > 0 ? FREG : 1], af1[FREG > 0 ? FREG : 1];
+    if (FREG > 0) {
+#pragma unroll
+        for (int f = 0; f < FREG; ++f) {
+            af0[f] = (f < F) ? fr[f * GP_TS + r0] : 0.0;
+            af1[f] = (f < F) ? fr[f * GP_TS + r0 + 16] : 0.0;
+        }
+    }
+
+    for (int l0 = 0; l0 < a.L; l0 += IM_NL) {
+        const int nl = min(IM_NL, a.L - l0);
+        const int nq = (nl + 15) >> 4;          // live 16-level sub-tiles of this pass (wave-uniform)
+        d4s acc[2][4], acck[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            acck[m] = (d4s){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[m][q] = (d4s){0.0, 0.0, 0.0, 0.0};
+        }
+        for (int c0 = 0; c0 < Np; c0 += IM_CC) {
+            __syncthreads();
+            const int FS = FREG > F ? FREG : F;      // staged feature rows (zero beyond F)
+            for (int idx = tid; idx < FS * IM_CC; idx += 256) {
+                const int f = idx / IM_CC, cc = idx - f * IM_CC;
+                const int g = c0 + cc;
+                fc[idx] = (f < F && g < n) ? feat_src(f)[g] * feat_il(f) : 0.0;
+            }
+            if (tid < IM_CC) {
+                const int g = c0 + tid;
+                tcs[tid] = (g < n) ? a.T[g] : 0.0;
+                al[tid] = (g < n) ? alpha[g] : 0.0;
+            }
+            for (int idx = tid; idx < IM_CC * IM_NL; idx += 256) {
+                const int cc = idx >> 6, ll = idx & 63;      // consecutive threads -> consecutive levels
+                const int g = c0 + cc;
+                double v = 0.0;
+                if (ll < nl && g < n) {
+                    const double dt = a.T[g] - a.doT[l0 + ll];
+                    v = gp_exp_neg(-((dt * dt) * wt)) * alpha[g];
+                }
+                R[cc * IM_RLD + ll] = v;
+            }
+            __syncthreads();
+            const double t0 = trs[r0], t1 = trs[r0 + 16];
+#pragma unroll 2
+            for (int kk = 0; kk < IM_CC / 4; ++kk) {
+                const int cc = 4 * kk + lq;            // this lane's column inside the chunk
+                double lux0 = 0.0, lux1 = 0.0;
+                if (FREG > 0) {
+#pragma unroll
+                    for (int f = 0; f < FREG; ++f) {       // fc rows beyond F are zero-filled
+                        const double cf = fc[f * IM_CC + cc];
+                        const double d0 = af0[f] - cf, d1 = af1[f] - cf;
+                        lux0 = fma(d0, d0, lux0);
+                        lux1 = fma(d1, d1, lux1);
+                    }
+                } else {
+                    for (int f = 0; f < F; ++f) {
+                        const double cf = fc[f * IM_CC + cc];
+                        const double d0 = fr[f * GP_TS + r0] - cf;
+                        const double d1 = fr[f * GP_TS + r0 + 16] - cf;
+                        lux0 = fma(d0, d0, lux0);
+                        lux1 = fma(d1, d1, lux1);
+                    }
+                }
+                const double tc = tcs[cc];
+                const double dt0 = t0 - tc, dt1 = t1 - tc;
+                const double B0 = ys * gp_exp_neg(-lux0), B1 = ys * gp_exp_neg(-lux1);
+                const double K0 = B0 * gp_exp_neg(-((dt0 * dt0) * wt)), K1 = B1 * gp_exp_neg(-((dt1 * dt1) * wt));
+                const double av = (li == 0) ? al[cc] : 0.0;       // alpha as a one-column right operand
+                const double* Rrow = R + cc * IM_RLD + li;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q < nq) {
+                        const double rf = Rrow[16 * q];
+                        acc[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, B0, acc[0][q], 0, 0, 0);
+                        acc[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, B1, acc[1][q], 0, 0, 0);
+                    }
+                }
+                acck[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, K0, acck[0], 0, 0, 0);
+                acck[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, K1, acck[1], 0, 0, 0);
+            }
+        }
+        // acc[m][q][v] = (B R)[row 32w + 16m + li][level 16q + lq + 4v]; (K alpha)[row] sits in lane li, v = 0
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const double ka = __shfl(acck[m][0], li, 64);
+            const int gi = ib * GP_TS + 32 * wave + 16 * m + li;
+            if (gi < n) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int ll = 16 * q + lq + 4 * v;
+                        if (ll < nl)
+                            a.meanITE[(long long)gi * a.si + s * a.ss + (long long)(l0 + ll) * a.sl] = acc[m][q][v] - ka;
+                    }
+            }
+        }
+    }
+}
+
+template <int FREG>
+static void launch_ite_mean_mfma_t(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+    const int F = a.nU + a.nX;
+    const int FS = FREG > F ? FREG : F;
+    const int bytes = (F * GP_TS + FS * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ite_mean_mfma_kernel<FREG>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (MAXF * GP_TS + MAXF * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ite_mean_mfma_kernel<FREG>, dim3(a.nt, nbatch), dim3(256), bytes, st, a);
+}
+static void launch_ite_mean_mfma(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+    const int F = a.nU + a.nX;
+    if (F <= 4) launch_ite_mean_mfma_t<4>(a, nbatch, st);
+    else if (F <= 12) launch_ite_mean_mfma_t<12>(a, nbatch, st);
+    else launch_ite_mean_mfma_t<0>(a, nbatch, st);
+}
+
 template <int FREG, int LCT, typename RT>
 static void launch_ite_mean_t(const IteMeanArgs& a, int nbatch, hipStream_t st) {
     const int bytes = (GP_TS + 2 * LCT * GP_TS) * 8 + (FREG * GP_TS + GP_TS) * (int)sizeof(RT);
@@ -205,6 +384,8 @@ static void launch_ite_mean_r(const IteMeanArgs& a, int nbatch, hipStream_t st) 
     else launch_ite_mean_f<32, RT>(a, nbatch, st);
 }
 void launch_ite_mean(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+    // many levels: the (B R) product belongs on the matrix cores (fp64 path; the fp32 mode keeps the VALU kernel)
+    if (!a.f32 && a.L > 4) { launch_ite_mean_mfma(a, nbatch, st); return; }
     if (a.f32) launch_ite_mean_r<float>(a, nbatch, st);
     else launch_ite_mean_r<double>(a, nbatch, st);
 }

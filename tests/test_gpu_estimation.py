@@ -340,3 +340,26 @@ def test_summarize_estimates_on_device(gp):
         assert np.array_equal(out["Individual"], np.arange(1, n + 1))
     with pytest.raises(gp.GPSLCError):
         gp.summarizeEstimates(np.zeros((2, 20000)))
+
+
+def test_multi_level_mfma_mean_ite_path(gp):
+    """L > 4 takes the MFMA-based MeanITE kernel: parity with the oracle and the exact-zero identity
+    (both MFMA chains see bit-identical operands when doT == T everywhere)."""
+    c = cases.make_case(300, "UX", False, S=3, seed=71)
+    doTs = np.linspace(float(c["T"].min()), float(c["T"].max()), 9)
+    obj = cases.gpslc_object(gp, c)
+    ms, vs, mi = gp.predict(obj, doTs, want_mean_ite=True)
+    exp = cases.oracle_expected(dict(c, doTs=doTs))
+    assert np.max(np.abs(mi - exp["meanITE"])) <= 1e-9 * np.max(np.abs(exp["meanITE"])) + 1e-13
+    assert np.max(np.abs(mi.mean(axis=0) - ms)) <= 1e-10 * np.max(np.abs(ms)) + 1e-13
+    # the single-level (VALU) kernel and the MFMA kernel agree level by level
+    for l in (0, 4, 8):
+        _, _, mi1 = gp.predict(obj, [doTs[l]], want_mean_ite=True)
+        assert np.max(np.abs(mi1[:, :, 0] - mi[:, :, l])) <= 1e-11 * np.max(np.abs(mi)) + 1e-14
+    n = 200
+    rng = np.random.default_rng(3)
+    T = np.full(n, 0.75)
+    g = gp.GPSLCObject(rng.standard_normal((n, 3)), T, rng.standard_normal(n), rng.standard_normal((n, 2, 2)),
+                       rng.uniform(0.5, 2, (2, 2)), rng.uniform(0.5, 2, (3, 2)), [0.8, 1.1], [0.6, 0.9], [1.1, 0.7])
+    ms, vs, mi = gp.predict(g, [0.75] * 6, want_mean_ite=True)
+    assert np.all(mi == 0.0) and np.all(ms == 0.0)
