@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-units", type=int, default=2)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--binary-t", action="store_true", help="Bernoulli(0.5) treatments (BASELINE config 5 shape)")
     ap.add_argument("--fp32-kernel", action="store_true", help="mixed precision: RBF evaluation in fp32 (config 5)")
     return ap.parse_args()
 
@@ -105,7 +106,7 @@ def main():
 
     n, D, K, L = a.n, a.d, a.nu, a.levels
     Sr = a.samples_per_step
-    X, T, Y, obj = synth.make_dataset(n, D)
+    X, T, Y, obj = synth.make_dataset(n, D, binary_t=a.binary_t)
     post = synth.make_posterior(n, D, K, Sr, obj, seed=1234 + 17 * rank)   # every rank owns different samples
     doT = synth.levels(T, L)
 
@@ -181,7 +182,8 @@ def main():
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if not a.fp32_kernel else "f64 factorisation, f32 kernel build", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo — not a result)" if rehearsal else ""),
             "config": {"workload": f"Synthetic N={n} D={D} nU={K}, unit A (Gram build + potrf + alpha + MeanITE + "
-                                   f"SATE mean/var), L={L} level(s), {Sr} posterior samples per GPU per step",
+                                   f"SATE mean/var), L={L} level(s), {Sr} posterior samples per GPU per step"
+                                   + (", binary treatment" if a.binary_t else ""),
                        "samples_per_gpu_per_step": Sr, "levels": L, "mean_ite": not a.no_mean_ite,
                        "sharding": f"posterior samples over {world} rank(s), all_gather of SATE at step end"},
         }

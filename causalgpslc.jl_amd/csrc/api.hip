@@ -56,6 +56,7 @@ struct gpslc_ctx {
     int nt = 0;
     double *dX = nullptr, *dT = nullptr, *dY = nullptr;
     bool has_data = false;
+    bool binary_t = false;   // every treatment is exactly 0 or 1 (detected in gpslc_set_data)
     int max_batch = 0;   // 0 = auto
     int panel = 8;
     int nstreams = 1;   // chunks of one call alternate over this many HIP streams (2 buys ~1-2 %, see profiles/)
@@ -378,6 +379,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         ga.n = n; ga.nX = io.nX; ga.nU = io.nU; ga.nt = nt; ga.M = M; ga.part = part;
         ga.with_sums = with_sums ? 1 : 0;
         ga.f32 = (c->flags & GPSLC_FLAG_FP32_KERNEL) ? 1 : 0;
+        ga.binary_t = (c->binary_t && io.nU == c->nU && io.nX == c->nX && io.Y == c->dY) ? 1 : 0;   // ctx data only
         launch_gram(ga, nb, st);
 
         RhsArgs ra{};
@@ -403,6 +405,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
             ia.X = io.X; ia.T = c->dT; ia.p = io.p; ia.s0 = s0; ia.S = io.S;
             ia.n = n; ia.nX = io.nX; ia.nU = io.nU; ia.nt = nt; ia.L = L; ia.doT = io.doT; ia.alpha = alpha;
             ia.f32 = (c->flags & GPSLC_FLAG_FP32_KERNEL) ? 1 : 0;
+            ia.binary_t = c->binary_t ? 1 : 0;
             if (meanITE) {
                 ia.meanITE = meanITE; ia.si = 1; ia.ss = n; ia.sl = (long long)n * io.S;
                 launch_ite_mean(ia, nb, st);
@@ -626,6 +629,10 @@ static int set_data_impl(gpslc_ctx* c, const double* X, const double* T, const d
         if (c->nX > 0) HC(hipMemcpy(c->dX, X, sizeof(double) * c->n * c->nX, kind));
         HC(hipMemcpy(c->dT, T, sizeof(double) * c->n, kind));
         HC(hipMemcpy(c->dY, Y, sizeof(double) * c->n, kind));
+        std::vector<double> hT(c->n);
+        HC(hipMemcpy(hT.data(), c->dT, sizeof(double) * c->n, hipMemcpyDeviceToHost));
+        c->binary_t = true;
+        for (double t : hT) if (t != 0.0 && t != 1.0) { c->binary_t = false; break; }
         c->has_data = true;
         return GPSLC_OK;
     });

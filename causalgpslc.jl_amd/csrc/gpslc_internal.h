@@ -68,6 +68,7 @@ struct GramArgs {
     double* part;      // [b][2][nt][Np] partial column sums of B (0) and K (1)
     int with_sums;
     int f32;           // evaluate the RBF kernel in fp32 (GPSLC_FLAG_FP32_KERNEL)
+    int binary_t;      // every T is 0 or 1: e_ij is 1 or exp(-1/tyLS^2), no per-pair exp (bit-identical)
 };
 
 // launchers (implemented in the k_*.hip files); all asynchronous on `st`
@@ -106,6 +107,7 @@ struct IteMeanArgs {
     double* meanITE;       // element (i, s, l) at i*si + s*ss + l*sl
     long long si, ss, sl;
     int f32;
+    int binary_t;
 };
 void launch_ite_mean(const IteMeanArgs& a, int nbatch, hipStream_t st);
 

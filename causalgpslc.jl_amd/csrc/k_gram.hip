@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     const double yn = g.p.yNoise[s];
     const double tl = g.p.tyLS[s];
     const RT wt = (RT)(1.0 / (tl * tl));
+    const RT ew = RbfMath<RT>::exp_neg(-wt);     // e_ij for |T_i - T_j| = 1 (binary treatments)
     const int ty = tid & 15, tx = tid >> 4;
 
     RT tra[8];
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
             const int gi = gi0 + rp;
             const RT dt = tra[p] - tcq;
             const RT Bq = (RT)ys * RbfMath<RT>::exp_neg(-lux[p]);
-            const RT Eq = RbfMath<RT>::exp_neg(-((dt * dt) * wt));
+            const RT Eq = g.binary_t ? (dt == (RT)0 ? (RT)1 : ew) : RbfMath<RT>::exp_neg(-((dt * dt) * wt));
             double Bv = (double)Bq;
             double Kv = (double)(Bq * Eq);
             double Av = Kv;

@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     const double tl = a.p.tyLS[s];
     const double wt = 1.0 / (tl * tl);
     const RT wtq = (RT)wt;
+    const RT ewq = RbfMath<RT>::exp_neg(-wtq);
     const RT tri = (RT)((gi < n) ? a.T[gi] : 0.0);
     const double* alpha = a.alpha + b * Np;
 
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
                 }
                 const RT dt = tri - tcs[c];
                 const double Bv = (double)((RT)ys * RbfMath<RT>::exp_neg(-lux));
-                const double Ev = (double)RbfMath<RT>::exp_neg(-((dt * dt) * wtq));
+                const double Ev = (double)(a.binary_t ? (dt == (RT)0 ? (RT)1 : ewq) : RbfMath<RT>::exp_neg(-((dt * dt) * wtq)));
                 const double ba = Bv * al[c];
 #pragma unroll
                 for (int ll = 0; ll < LCT; ++ll) acc[ll] = fma(ba, rl[ll * GP_TS + c] - Ev, acc[ll]);
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
     const double tl = a.p.tyLS[s];
     const double wt = 1.0 / (tl * tl);
     const double* alpha = a.alpha + b * Np;
+    const double ew = gp_exp_neg(-wt);
     const int r0 = 32 * wave + li;           // this lane's rows: r0 and r0 + 16
     __syncthreads();
     double af0[FREG > 0 ? FREG : 1], af1[FREG > 0 ? FREG : 1];
@@ -303,7 +305,9 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
                 const double tc = tcs[cc];
                 const double dt0 = t0 - tc, dt1 = t1 - tc;
                 const double B0 = ys * gp_exp_neg(-lux0), B1 = ys * gp_exp_neg(-lux1);
-                const double K0 = B0 * gp_exp_neg(-((dt0 * dt0) * wt)), K1 = B1 * gp_exp_neg(-((dt1 * dt1) * wt));
+                const double E0 = a.binary_t ? (dt0 == 0.0 ? 1.0 : ew) : gp_exp_neg(-((dt0 * dt0) * wt));
+                const double E1 = a.binary_t ? (dt1 == 0.0 ? 1.0 : ew) : gp_exp_neg(-((dt1 * dt1) * wt));
+                const double K0 = B0 * E0, K1 = B1 * E1;
                 const double av = (li == 0) ? al[cc] : 0.0;       // alpha as a one-column right operand
                 const double* Rrow = R + cc * IM_RLD + li;
 #pragma unroll
