@@ -118,3 +118,23 @@ def test_config5_n16384_d16_nu4_binary(gp):
     # binary T: an instance already at the intervention level has r_j == e_ij for its own row only; the
     # ITE of "doT = its own treatment" is not zero in general, but MeanSATE(0) and MeanSATE(1) differ
     assert np.all(np.abs(ms[:, 0] - ms[:, 1]) > 0)
+
+
+def test_config4_shape_n4096_64_levels(gp):
+    """BASELINE configs[3] shape on one rank: N=4096, 64 intervention levels (the sample axis shards over
+    GPUs, tests/test_sharded_gloo.py).  All 64 levels share one factorisation; the level sweep of MeanITE runs
+    on the MFMA kernel."""
+    n, D, K, S, L = 4096, 8, 2, 6, 64
+    g, data = _obj(gp, n, D, K, S)
+    doTs = gp.synth.levels(data[1], L)
+    ms, vs, mi = gp.predict(g, doTs, want_mean_ite=True)
+    assert ms.shape == (S, L) and mi.shape == (n, S, L)
+    assert np.all(np.isfinite(mi)) and np.all(vs > 0)
+    assert np.max(np.abs(mi.mean(axis=0) - ms)) <= 1e-10 * np.max(np.abs(ms)) + 1e-13
+    p = _sample(data[3], 2, D, K)
+    rm, rv, _, _ = orc.structured_sate(p, data[0], data[1], data[2], doTs)
+    assert np.max(np.abs(ms[2] - rm) / np.abs(rm)) <= 1e-9
+    assert np.all(np.abs(vs[2] - rv) <= 1e-8 * np.abs(rv) + 1e-12 * p.yScale)
+    # SATE-only call (no back-substitution / MeanITE pass) gives the same numbers
+    ms2, vs2, _ = gp.predict(g, doTs)
+    assert np.array_equal(ms2, ms) and np.array_equal(vs2, vs)

@@ -1,0 +1,44 @@
+"""Randomised shapes through the C ABI against the oracle's structured restatement: n (incl. tile
+boundaries), nU, nX, S, number of levels, treatment type, tuning knobs."""
+import numpy as np
+import pytest
+
+import gpslc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes(gp, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 5, 17, 64, 127, 128, 129, 200, 255, 256, 257, 300, 385]))
+    nU = int(rng.integers(0, 5))
+    nX = int(rng.integers(0, 7))
+    S = int(rng.integers(1, 6))
+    L = int(rng.choice([1, 2, 3, 5, 9, 17]))
+    binary = bool(rng.integers(0, 2))
+    X = rng.standard_normal((n, nX)) if nX else None
+    T = (rng.random(n) < 0.5).astype(float) if binary else rng.standard_normal(n)
+    Y = rng.standard_normal(n)
+    ig = lambda size: np.maximum(4.0 / rng.gamma(4.0, 1.0, size=size), 0.3)   # noqa: E731
+    U = rng.standard_normal((n, nU, S)) if nU else None
+    uyLS = ig((nU, S)) if nU else None
+    xyLS = ig((nX, S)) if nX else None
+    tyLS, yNoise, yScale = ig(S), ig(S), ig(S)
+    doTs = rng.uniform(-1.5, 1.5, L)
+    if binary:
+        doTs[0] = 1.0
+    g = gp.GPSLCObject(X, T, Y, U, uyLS, xyLS, tyLS, yNoise, yScale)
+    g.ctx().set_tuning(int(rng.choice([0, 1, 2, 3])), int(rng.choice([0, 1, 2, 5])), int(rng.choice([0, 1, 2])))
+    ms, vs, mi = gp.predict(g, doTs, want_mean_ite=True)
+    lp = gp.yLogpdf(g)
+    for s in range(S):
+        p = orc.PosteriorSample(None if nU == 0 else uyLS[:, s], None if nX == 0 else xyLS[:, s], float(tyLS[s]),
+                                float(yNoise[s]), float(yScale[s]), None if nU == 0 else U[:, :, s])
+        rm, rv, logdet, quad = orc.structured_sate(p, X, T, Y, doTs)
+        assert np.all(np.abs(ms[s] - rm) <= 1e-9 * np.abs(rm) + 1e-13), (n, nU, nX, S, L, binary)
+        assert np.all(np.abs(vs[s] - rv) <= 1e-8 * np.abs(rv) + 1e-12 * p.yScale)
+        assert abs(lp[s] - (-0.5 * (n * np.log(2 * np.pi) + logdet + quad))) <= 1e-10 * abs(lp[s]) + 1e-10
+        for l in range(min(L, 3)):
+            m, _ = orc.structured_ite(p, X, T, Y, doTs[l])
+            assert np.max(np.abs(mi[:, s, l] - m)) <= 1e-9 * np.max(np.abs(m)) + 1e-13
