@@ -1,11 +1,11 @@
 """Host-side posterior inference for the no-covariates continuous-treatment model, scoring every
 Gaussian-process node on the GPU (BASELINE config 0).
 
-Mirrors, for ``CausalGPSLCNoCovRealT`` (src/model.jl:45-57):
+Mirrors, for ``CausalGPSLCRealT`` (src/model.jl:11-27) and ``CausalGPSLCNoCovRealT`` (src/model.jl:45-57):
 
     getPriorParameters / getHyperParameters      src/hyperparameters.jl:38-70, 85-102
     generateSigmaU, prepareData                  src/utils.jl:17-33, src/data.jl:20-70
-    Posterior(priorparams, nothing, T, Y, ...)   src/inference.jl:62-102  (MH within Gibbs + elliptical slice)
+    Posterior(priorparams, X | nothing, T, Y, ...) src/inference.jl:4-59, 62-102  (MH within Gibbs + elliptical slice)
     paramProposal                                src/proposal.jl:32-41    (moment-matched InvGamma drift)
     gpslc                                        src/driver.jl:27-33, 59-69
 
@@ -18,7 +18,7 @@ Not bit-comparable with the reference: Gen 0.4.4 and Julia's RNG are unavailable
 NumPy's Philox generator and the textbook algorithms (Metropolis-Hastings ratio with the asymmetric InvGamma
 proposal; elliptical slice sampling, Murray et al. 2010, with the likelihood = the :T and :Y scores).  The
 reference's own acceptance test for this path is statistical (test/driver.jl:45-52) and is reproduced in
-tests/test_gpu_neec.py.  The other seven model variants are not built yet (NotImplementedError).
+tests/test_gpu_neec.py.  The no-U and the binary-treatment variants are not built yet (NotImplementedError).
 """
 from __future__ import annotations
 
@@ -126,29 +126,35 @@ def toMatrixModel(Ucols, n, nU):
     return np.asfortranarray(H.T.reshape(-1, order="F").reshape(n, nU, order="F"))
 
 
-class _NoCovRealTChain:
-    """State + node scores of CausalGPSLCNoCovRealT (src/model.jl:45-57)."""
+class _RealTChain:
+    """State + node scores of CausalGPSLCRealT (src/model.jl:11-27; X given) and CausalGPSLCNoCovRealT
+    (src/model.jl:45-57; X is None)."""
 
-    SCALARS = ("uNoise", "tNoise", "yNoise", "tyLS", "tScale", "yScale")
-
-    def __init__(self, priorparams, SigmaU, T, Y, nU, rng, device=0):
-        self.pp, self.SigmaU, self.T, self.Y, self.nU, self.rng = priorparams, SigmaU, T, Y, nU, rng
+    def __init__(self, priorparams, SigmaU, X, T, Y, nU, rng, device=0):
+        self.pp, self.SigmaU, self.X, self.T, self.Y, self.nU, self.rng = priorparams, SigmaU, X, T, Y, nU, rng
         self.n = len(Y)
+        self.nX = 0 if X is None else X.shape[1]
         self.ctx = Context(self.n, 0, 0, device=device)
         self.ctx.set_data(None, np.zeros(self.n), np.zeros(self.n))
         api.mvnLogpdf(SigmaU, np.zeros((self.n, 0)), ctx=self.ctx)        # factor SigmaU once (cached)
         self.Lsig = np.linalg.cholesky(SigmaU)                            # for the slice's auxiliary draw
         ig = lambda name: priorparams[name + "Scale"] / rng.gamma(priorparams[name + "Shape"])   # noqa: E731
-        # generate(): latent addresses from the prior (src/inference.jl:75), :T and :Y constrained
-        self.v = {k: ig(k) for k in self.SCALARS}
-        self.v["utLS"] = np.array([ig("utLS") for _ in range(nU)])
-        self.v["uyLS"] = np.array([ig("uyLS") for _ in range(nU)])
-        self.U = [math.sqrt(self.v["uNoise"]) * (self.Lsig @ rng.standard_normal(self.n)) for _ in range(nU)]
+        # generate(): latent addresses from the prior (src/inference.jl:20, :75); :T, :Y (and :X => k => :X) constrained
+        v = {k: ig(k) for k in ("uNoise", "tNoise", "yNoise", "tyLS", "tScale", "yScale")}
+        v["utLS"] = np.array([ig("utLS") for _ in range(nU)])
+        v["uyLS"] = np.array([ig("uyLS") for _ in range(nU)])
+        if self.nX:
+            v["uxLS"] = np.array([[ig("uxLS") for _ in range(self.nX)] for _ in range(nU)])   # [u][k]: :uxLS => u => k
+            for name in ("xNoise", "xtLS", "xyLS", "xScale"):
+                v[name] = np.array([ig(name) for _ in range(self.nX)])
+        self.v = v
+        self.U = [math.sqrt(v["uNoise"]) * (self.Lsig @ rng.standard_normal(self.n)) for _ in range(nU)]
         self.s_u = self.score_u()
+        self.s_x = self.score_x()            # array over k (empty without covariates)
         self.s_t = self.score_t()
         self.s_y = self.score_y()
 
-    # node scores (GPU)
+    # ---- node scores (GPU) ------------------------------------------------------------------------
     def score_u(self, uNoise=None, U=None):
         U = self.U if U is None else U
         un = self.v["uNoise"] if uNoise is None else uNoise
@@ -157,43 +163,73 @@ class _NoCovRealTChain:
     def _umodel(self, U=None):
         return toMatrixModel(self.U if U is None else U, self.n, self.nU)
 
-    def score_t(self, v=None, U=None):   # generateRealTfromU, src/model_likelihood.jl:55-60
-        v = v or self.v
-        return float(api.gpLogpdf(self._umodel(U), v["utLS"], v["tScale"], v["tNoise"], self.T, ctx=self.ctx)[0])
+    def _uxls_model(self, v):
+        """`toMatrix(uxLS, nX, nU)` of src/model_prior.jl:110 -> (nX, nU); row k feeds X node k."""
+        return toMatrixModel([v["uxLS"][u] for u in range(self.nU)], self.nX, self.nU)
 
-    def score_y(self, v=None, U=None):   # generateYfromUT, src/model_likelihood.jl:94-101
+    def score_x(self, v=None, U=None, only=None):
+        """:X => k => :X for every covariate in ONE batched call (generateXfromU, src/model_likelihood.jl:13-22)."""
+        if not self.nX:
+            return np.zeros(0)
         v = v or self.v
-        F = np.column_stack([self._umodel(U), self.T])
-        return float(api.gpLogpdf(F, np.concatenate([v["uyLS"], [v["tyLS"]]]), v["yScale"], v["yNoise"], self.Y,
-                                  ctx=self.ctx)[0])
+        ls = self._uxls_model(v)                                  # (nX, nU)
+        ks = range(self.nX) if only is None else [only]
+        out = api.gpLogpdf(self._umodel(U), np.column_stack([ls[k] for k in ks]), v["xScale"][list(ks)],
+                           v["xNoise"][list(ks)], self.X[:, list(ks)], ctx=self.ctx)
+        return out if only is None else float(out[0])
 
-    # which node scores an address touches
+    def score_t(self, v=None, U=None):   # generateRealTfromUX / fromU, src/model_likelihood.jl:36-44, 55-60
+        v = v or self.v
+        F = self._umodel(U) if not self.nX else np.column_stack([self._umodel(U), self.X])
+        ls = v["utLS"] if not self.nX else np.concatenate([v["utLS"], v["xtLS"]])
+        return float(api.gpLogpdf(F, ls, v["tScale"], v["tNoise"], self.T, ctx=self.ctx)[0])
+
+    def score_y(self, v=None, U=None):   # generateYfromUXT / UT, src/model_likelihood.jl:83-101
+        v = v or self.v
+        cols = [self._umodel(U)] + ([self.X] if self.nX else []) + [self.T]
+        ls = np.concatenate([v["uyLS"]] + ([v["xyLS"]] if self.nX else []) + [[v["tyLS"]]])
+        return float(api.gpLogpdf(np.column_stack(cols), ls, v["yScale"], v["yNoise"], self.Y, ctx=self.ctx)[0])
+
+    # which node an address touches
     TOUCH = {"uNoise": "u", "tNoise": "t", "yNoise": "y", "tyLS": "y", "tScale": "t", "yScale": "y",
-             "utLS": "t", "uyLS": "y"}
+             "utLS": "t", "uyLS": "y", "uxLS": "x", "xNoise": "x", "xScale": "x", "xtLS": "t", "xyLS": "y"}
 
-    def mh(self, name, k=None):
-        """One `mh(trace, paramProposal, (drift, addr))` (src/inference.jl:78-89)."""
-        prior = name
-        cur = self.v[name] if k is None else self.v[name][k]
+    def mh(self, name, i=None, j=None):
+        """One `mh(trace, paramProposal, (drift, addr))` (src/inference.jl:22-45, :78-89): `i`, `j` as in
+        getProposalAddress (src/proposal.jl:7-24), 0-based here."""
+        cur = self.v[name] if i is None else (self.v[name][i] if j is None else self.v[name][i][j])
         sh, sc = _proposal_params(cur, self.pp["drift"])
         new = sc / self.rng.gamma(sh)
         shb, scb = _proposal_params(new, self.pp["drift"])
         v2 = dict(self.v)
-        if k is None:
-            v2[name] = new
-        else:
+        if i is not None:
             arr = self.v[name].copy()
-            arr[k] = new
+            if j is None:
+                arr[i] = new
+            else:
+                arr[i][j] = new
             v2[name] = arr
+        else:
+            v2[name] = new
         node = self.TOUCH[name]
-        old_s = {"u": self.s_u, "t": self.s_t, "y": self.s_y}[node]
+        xk = (j if name == "uxLS" else i) if node == "x" else None
+        old_s = {"u": self.s_u, "t": self.s_t, "y": self.s_y}.get(node)
+        if node == "x":
+            old_s = self.s_x[xk]
         try:
-            new_s = (self.score_u(uNoise=new) if node == "u" else self.score_t(v2) if node == "t" else self.score_y(v2))
+            if node == "u":
+                new_s = self.score_u(uNoise=new)
+            elif node == "t":
+                new_s = self.score_t(v2)
+            elif node == "y":
+                new_s = self.score_y(v2)
+            else:
+                new_s = self.score_x(v2, only=xk)
         except api.PosDefException:
             return False
         log_a = (new_s - old_s
-                 + _invgamma_logpdf(new, self.pp[prior + "Shape"], self.pp[prior + "Scale"])
-                 - _invgamma_logpdf(cur, self.pp[prior + "Shape"], self.pp[prior + "Scale"])
+                 + _invgamma_logpdf(new, self.pp[name + "Shape"], self.pp[name + "Scale"])
+                 - _invgamma_logpdf(cur, self.pp[name + "Shape"], self.pp[name + "Scale"])
                  + _invgamma_logpdf(cur, shb, scb) - _invgamma_logpdf(new, sh, sc))
         if math.log(self.rng.random()) < log_a:
             self.v = v2
@@ -201,15 +237,18 @@ class _NoCovRealTChain:
                 self.s_u = new_s
             elif node == "t":
                 self.s_t = new_s
-            else:
+            elif node == "y":
                 self.s_y = new_s
+            else:
+                self.s_x = self.s_x.copy()
+                self.s_x[xk] = new_s
             return True
         return False
 
     def elliptical_slice(self, k):
-        """`elliptical_slice(trace, :U => k => :U, zeros(n), uCov)` (src/inference.jl:92-98)."""
+        """`elliptical_slice(trace, :U => k => :U, zeros(n), uCov)` (src/inference.jl:48-54, :92-98)."""
         nu = math.sqrt(self.v["uNoise"]) * (self.Lsig @ self.rng.standard_normal(self.n))
-        log_y = self.s_t + self.s_y + math.log(self.rng.random())
+        log_y = float(np.sum(self.s_x)) + self.s_t + self.s_y + math.log(self.rng.random())
         theta = self.rng.uniform(0.0, 2.0 * math.pi)
         lo, hi = theta - 2.0 * math.pi, theta
         f = self.U[k]
@@ -218,11 +257,11 @@ class _NoCovRealTChain:
             U2 = list(self.U)
             U2[k] = prop
             try:
-                st, sy = self.score_t(U=U2), self.score_y(U=U2)
+                sx, st, sy = self.score_x(U=U2), self.score_t(U=U2), self.score_y(U=U2)
             except api.PosDefException:
-                st = sy = -math.inf
-            if st + sy > log_y:
-                self.U, self.s_t, self.s_y = U2, st, sy
+                sx, st, sy = np.zeros(0), -math.inf, -math.inf
+            if float(np.sum(sx)) + st + sy > log_y:
+                self.U, self.s_x, self.s_t, self.s_y = U2, sx, st, sy
                 self.s_u = self.score_u()
                 return
             if theta < 0:
@@ -232,28 +271,39 @@ class _NoCovRealTChain:
             theta = self.rng.uniform(lo, hi)
         # bracket collapsed onto the current state: keep it
 
+    def sweep_mh(self):
+        """One inner sweep in the reference's address order (src/inference.jl:23-44 / :78-89)."""
+        self.mh("uNoise"); self.mh("tNoise"); self.mh("yNoise"); self.mh("tyLS")        # noqa: E702
+        for k in range(self.nU):
+            self.mh("utLS", k); self.mh("uyLS", k)                                      # noqa: E702
+            for l in range(self.nX):
+                self.mh("uxLS", k, l)
+        for k in range(self.nX):
+            self.mh("xNoise", k); self.mh("xtLS", k); self.mh("xyLS", k); self.mh("xScale", k)   # noqa: E702
+        self.mh("tScale"); self.mh("yScale")                                            # noqa: E702
+
     def snapshot(self):
-        return {"uNoise": self.v["uNoise"], "tNoise": self.v["tNoise"], "yNoise": self.v["yNoise"],
-                "tyLS": self.v["tyLS"], "tScale": self.v["tScale"], "yScale": self.v["yScale"],
-                "utLS": self.v["utLS"].copy(), "uyLS": self.v["uyLS"].copy(), "U": [u.copy() for u in self.U]}
+        out = {k: (val.copy() if isinstance(val, np.ndarray) else val) for k, val in self.v.items()}
+        out["U"] = [u.copy() for u in self.U]
+        return out
 
 
 def Posterior(priorparams, X, T, Y, nU, nOuter, nMHInner, nESInner, seed=1234, device=0):
-    """Posterior(priorparams, nothing, T::ContinuousTreatment, Y, nU, nOuter, nMHInner, nESInner)
-    (src/inference.jl:62-102).  Returns the list of nOuter posterior samples (dicts keyed like the trace)."""
-    if X is not None or nU is None or np.asarray(T).dtype == np.bool_:
-        raise NotImplementedError("only CausalGPSLCNoCovRealT (latent confounders, no covariates, continuous "
-                                  "treatment) is built so far; see DESIGN.md")
+    """Posterior(priorparams, X or nothing, T::ContinuousTreatment, Y, nU, nOuter, nMHInner, nESInner)
+    (src/inference.jl:4-59 with covariates, :62-102 without).  Returns the list of nOuter posterior samples
+    (dicts keyed like the trace)."""
+    if nU is None or priorparams.get("SigmaU") is None or np.asarray(T).dtype == np.bool_:
+        raise NotImplementedError("built so far: the continuous-treatment models with latent confounders "
+                                  "(CausalGPSLCRealT, CausalGPSLCNoCovRealT); no-U and binary-treatment variants "
+                                  "are not — see DESIGN.md")
     rng = np.random.Generator(np.random.Philox(seed))
-    ch = _NoCovRealTChain(priorparams, priorparams["SigmaU"], np.asarray(T, float), np.asarray(Y, float), nU, rng,
-                          device=device)
+    Xa = None if X is None else np.asarray(X, float).reshape(len(Y), -1)
+    ch = _RealTChain(priorparams, priorparams["SigmaU"], Xa, np.asarray(T, float), np.asarray(Y, float), nU, rng,
+                     device=device)
     samples = []
     for _ in range(nOuter):
         for _ in range(nMHInner):
-            ch.mh("uNoise"); ch.mh("tNoise"); ch.mh("yNoise"); ch.mh("tyLS")        # noqa: E702
-            for k in range(nU):
-                ch.mh("utLS", k); ch.mh("uyLS", k)                                      # noqa: E702
-            ch.mh("tScale"); ch.mh("yScale")                                            # noqa: E702
+            ch.sweep_mh()
         for _ in range(nESInner):
             for k in range(nU):
                 ch.elliptical_slice(k)
@@ -278,7 +328,8 @@ def gpslc(data, hyperparams: Optional[HyperParameters] = None, priorparams: Opti
     for s, smp in enumerate(keep):
         for u in range(nU):
             U[:, u, s] = smp["U"][u]                        # extractParameters: no interleave (src/utils.jl:103-106)
-    g = GPSLCObject(None, T, Y, U, np.column_stack([smp["uyLS"] for smp in keep]), None,
+    xyLS = None if X is None else np.column_stack([smp["xyLS"] for smp in keep])
+    g = GPSLCObject(X, T, Y, U, np.column_stack([smp["uyLS"] for smp in keep]), xyLS,
                     np.array([smp["tyLS"] for smp in keep]), np.array([smp["yNoise"] for smp in keep]),
                     np.array([smp["yScale"] for smp in keep]), hyperparams=hp, device=device)
     g.posteriorSamples = post

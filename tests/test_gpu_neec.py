@@ -47,7 +47,7 @@ def test_chain_moves_and_scores_are_consistent(gp):
     pp = gp.getPriorParameters()
     pp["SigmaU"] = SigmaU
     rng = np.random.Generator(np.random.Philox(5))
-    ch = inf._NoCovRealTChain(pp, SigmaU, T, Y, 2, rng)
+    ch = inf._RealTChain(pp, SigmaU, None, T, Y, 2, rng)
     before = ch.snapshot()
     acc = 0
     for _ in range(3):
@@ -63,3 +63,47 @@ def test_chain_moves_and_scores_are_consistent(gp):
     # the model-side interleave of U for nU = 2: column-major reshape of the transposed stack
     Um = gp.toMatrixModel([np.arange(4.0), 10 + np.arange(4.0)], 4, 2)
     assert np.array_equal(Um, np.array([[0, 2], [10, 12], [1, 3], [11, 13]], dtype=float))
+
+
+GOLD = os.path.join(HERE, "golden", "neec")
+
+
+@pytest.mark.parametrize("csvname,n,nX", [("additive_linear.csv", 200, 3), ("minimal.csv", 24, 2), ("no_cov.csv", 25, 0)])
+def test_gpslc_runs_on_reference_csvs(gp, csvname, n, nX):
+    """test/gpslc.jl:1-22 / test/driver.jl:1-7: gpslc() on the reference's CSV shapes that have object labels
+    and a continuous treatment, followed by the prediction entry points."""
+    path = os.path.join(GOLD, csvname)
+    SigmaU, obj, X, T, Y = gp.prepareData(path)
+    if nX is None:
+        nX = 0 if X is None else X.shape[1]
+    hp = gp.HyperParameters(nU=2, nOuter=6, nMHInner=2, nESInner=2, nBurnIn=3)
+    g = gp.gpslc(path, hyperparams=hp, seed=3)
+    assert gp.getN(g) == n and gp.getNX(g) == nX and gp.getNU(g) == 2 and gp.getNumPosteriorSamples(g) == 4
+    for arr in (g.tyLS, g.yNoise, g.yScale, g.uyLS, g.U):
+        assert np.all(np.isfinite(arr))
+    if nX:
+        assert g.xyLS.shape == (nX, 4) and np.all(g.xyLS > 0)
+    ite = gp.sampleITE(g, float(np.median(T)), samplesPerPosterior=3, seed=1)
+    assert ite.shape == (n, 12) and np.all(np.isfinite(ite))
+    sate = gp.sampleSATE(g, float(np.median(T)), samplesPerPosterior=3, seed=1)
+    assert sate.shape == (12,) and np.all(np.isfinite(sate))
+
+
+def test_full_model_chain_scores_are_consistent(gp):
+    from causalgpslc_jl_amd import inference as inf
+    SigmaU, obj, X, T, Y = gp.prepareData(os.path.join(GOLD, "additive_linear.csv"), 1e-6)
+    pp = gp.getPriorParameters()
+    pp["SigmaU"] = SigmaU
+    ch = inf._RealTChain(pp, SigmaU, X, T, Y, 2, np.random.Generator(np.random.Philox(11)))
+    before = ch.snapshot()
+    for _ in range(2):
+        ch.sweep_mh()
+        for k in range(2):
+            ch.elliptical_slice(k)
+    after = ch.snapshot()
+    assert any(not np.array_equal(before[k], after[k]) for k in ("uxLS", "xNoise", "xtLS", "xyLS", "xScale"))
+    assert np.allclose(ch.s_x, ch.score_x(), rtol=1e-12) and len(ch.s_x) == 3
+    assert np.isclose(ch.s_t, ch.score_t(), rtol=1e-12) and np.isclose(ch.s_y, ch.score_y(), rtol=1e-12)
+    # model-side reshape of uxLS (src/model_prior.jl:110): nU traced vectors of length nX -> (nX, nU), interleaved
+    v = {"uxLS": np.array([[1.0, 2.0, 3.0], [10.0, 20.0, 30.0]])}
+    assert np.array_equal(ch._uxls_model(v), np.array([[1.0, 20.0], [10.0, 3.0], [2.0, 30.0]]))
