@@ -1,7 +1,9 @@
 """Host-side posterior inference for the no-covariates continuous-treatment model, scoring every
 Gaussian-process node on the GPU (BASELINE config 0).
 
-Mirrors, for ``CausalGPSLCRealT`` (src/model.jl:11-27) and ``CausalGPSLCNoCovRealT`` (src/model.jl:45-57):
+Mirrors, for the four models with latent confounders — ``CausalGPSLCRealT`` / ``NoCovRealT`` (src/model.jl:11-27,
+45-57, chains src/inference.jl:4-102) and ``CausalGPSLCBinaryT`` / ``NoCovBinaryT`` (src/model.jl:73-89, 109-120,
+chains src/inference.jl:169-302):
 
     getPriorParameters / getHyperParameters      src/hyperparameters.jl:38-70, 85-102
     generateSigmaU, prepareData                  src/utils.jl:17-33, src/data.jl:20-70
@@ -18,7 +20,8 @@ Not bit-comparable with the reference: Gen 0.4.4 and Julia's RNG are unavailable
 NumPy's Philox generator and the textbook algorithms (Metropolis-Hastings ratio with the asymmetric InvGamma
 proposal; elliptical slice sampling, Murray et al. 2010, with the likelihood = the :T and :Y scores).  The
 reference's own acceptance test for this path is statistical (test/driver.jl:45-52) and is reproduced in
-tests/test_gpu_neec.py.  The no-U and the binary-treatment variants are not built yet (NotImplementedError).
+tests/test_gpu_neec.py.  In the four no-U models the reference never constrains ``:X => k => :X`` (its
+trace holds a prior draw of X, src/inference.jl:117-123); here X is the data, as in prediction.
 """
 from __future__ import annotations
 
@@ -127,35 +130,99 @@ def toMatrixModel(Ucols, n, nU):
 
 
 class _RealTChain:
-    """State + node scores of CausalGPSLCRealT (src/model.jl:11-27; X given) and CausalGPSLCNoCovRealT
-    (src/model.jl:45-57; X is None)."""
+    """State + node scores of the four models with latent confounders: CausalGPSLCRealT / NoCovRealT
+    (src/model.jl:11-27, 45-57) and, with ``binary=True``, CausalGPSLCBinaryT / NoCovBinaryT (:73-89, 109-120)."""
 
-    def __init__(self, priorparams, SigmaU, X, T, Y, nU, rng, device=0):
+    def __init__(self, priorparams, SigmaU, X, T, Y, nU, rng, device=0, binary=False):
+        self.binary = binary          # CausalGPSLCBinaryT / NoCovBinaryT (src/model.jl:73-89, 109-120)
+        self.Tb = np.asarray(T).astype(bool) if binary else None
+        T = np.asarray(T, dtype=np.float64)   # Bool treatments promote to 0.0 / 1.0 in the :Y kernel
+        nU = nU or 0                      # nU::Nothing -> the NoU models (src/model.jl:28-41, 58-67, 91-106, 122-131)
         self.pp, self.SigmaU, self.X, self.T, self.Y, self.nU, self.rng = priorparams, SigmaU, X, T, Y, nU, rng
         self.n = len(Y)
         self.nX = 0 if X is None else X.shape[1]
         self.ctx = Context(self.n, 0, 0, device=device)
         self.ctx.set_data(None, np.zeros(self.n), np.zeros(self.n))
-        api.mvnLogpdf(SigmaU, np.zeros((self.n, 0)), ctx=self.ctx)        # factor SigmaU once (cached)
-        self.Lsig = np.linalg.cholesky(SigmaU)                            # for the slice's auxiliary draw
+        if nU:
+            api.mvnLogpdf(SigmaU, np.zeros((self.n, 0)), ctx=self.ctx)    # factor SigmaU once (cached)
+            self.Lsig = np.linalg.cholesky(SigmaU)                        # for the slice's auxiliary draw
         ig = lambda name: priorparams[name + "Scale"] / rng.gamma(priorparams[name + "Shape"])   # noqa: E731
         # generate(): latent addresses from the prior (src/inference.jl:20, :75); :T, :Y (and :X => k => :X) constrained
-        v = {k: ig(k) for k in ("uNoise", "tNoise", "yNoise", "tyLS", "tScale", "yScale")}
-        v["utLS"] = np.array([ig("utLS") for _ in range(nU)])
-        v["uyLS"] = np.array([ig("uyLS") for _ in range(nU)])
+        v = {k: ig(k) for k in ("yNoise", "tyLS", "yScale")}
+        if nU or self.nX:                 # the :T node has hyper-parameters only when something feeds it
+            v.update({k: ig(k) for k in ("tNoise", "tScale")})
+        if nU:
+            v["uNoise"] = ig("uNoise")
+            v["utLS"] = np.array([ig("utLS") for _ in range(nU)])
+            v["uyLS"] = np.array([ig("uyLS") for _ in range(nU)])
         if self.nX:
+            for name in ("xtLS", "xyLS"):
+                v[name] = np.array([ig(name) for _ in range(self.nX)])
+        if self.nX and nU:
             v["uxLS"] = np.array([[ig("uxLS") for _ in range(self.nX)] for _ in range(nU)])   # [u][k]: :uxLS => u => k
-            for name in ("xNoise", "xtLS", "xyLS", "xScale"):
+            for name in ("xNoise", "xScale"):
                 v[name] = np.array([ig(name) for _ in range(self.nX)])
         self.v = v
         self.U = [math.sqrt(v["uNoise"]) * (self.Lsig @ rng.standard_normal(self.n)) for _ in range(nU)]
+        if binary:                        # :logitT from its prior, the :T => i => :T nodes are constrained
+            self.logitT = np.linalg.cholesky(self._t_cov()) @ rng.standard_normal(self.n)
         self.s_u = self.score_u()
         self.s_x = self.score_x()            # array over k (empty without covariates)
         self.s_t = self.score_t()
         self.s_y = self.score_y()
+        self.s_b = self.score_b() if binary else 0.0
+
+    # ---- binary treatments: :logitT ~ mvnormal(0, logitTCov), :T => i => :T ~ bernoulli(expit(logitT_i))
+    def _t_features(self, U=None, v=None):
+        """Features and lengthscales of the :T / :logitT node: [U, X], [U], [X] or nothing (T ~ N(0, I))."""
+        v = v or self.v
+        cols = ([self._umodel(U)] if self.nU else []) + ([self.X] if self.nX else [])
+        ls = ([v["utLS"]] if self.nU else []) + ([v["xtLS"]] if self.nX else [])
+        if not cols:
+            return np.zeros((self.n, 0)), np.zeros(0)
+        return np.column_stack(cols), np.concatenate(ls)
+
+    def _t_cov(self):
+        """logitTCov = processCov(utCovLog + xtCovLog, tScale, tNoise) (src/model_likelihood.jl:25-33) on the host
+        — needed as a matrix only to draw the slice's auxiliary vector (src/inference.jl:216-227).  The model's
+        own (interleaved) U is used so that the ellipse is the prior of the node it moves."""
+        F, ls = self._t_features()
+        if not F.shape[1]:
+            return np.eye(self.n)         # generateBinaryTfromPrior, src/model_prior.jl:195-200
+        Fs = F / ls[None, :]
+        sq = np.sum(Fs * Fs, axis=1)
+        d2 = np.maximum(sq[:, None] + sq[None, :] - 2.0 * (Fs @ Fs.T), 0.0)
+        return self.v["tScale"] * np.exp(-d2) + self.v["tNoise"] * np.eye(self.n)
+
+    def score_b(self, logitT=None):
+        """sum_i log bernoulli(T_i; expit(logitT_i)) (generateBinaryT, src/model_prior.jl:21-24) — host scalar work."""
+        l = self.logitT if logitT is None else logitT
+        return float(-np.sum(np.logaddexp(0.0, np.where(self.Tb, -l, l))))
+
+    def elliptical_slice_logitT(self):
+        """`elliptical_slice(trace, :logitT, zeros(n), logitTCov)` (src/inference.jl:232)."""
+        nu = np.linalg.cholesky(self._t_cov()) @ self.rng.standard_normal(self.n)
+        log_y = self.s_b + math.log(self.rng.random())
+        theta = self.rng.uniform(0.0, 2.0 * math.pi)
+        lo, hi = theta - 2.0 * math.pi, theta
+        f = self.logitT
+        for _ in range(200):
+            prop = f * math.cos(theta) + nu * math.sin(theta)
+            sb = self.score_b(prop)
+            if sb > log_y:
+                self.logitT, self.s_b = prop, sb
+                self.s_t = self.score_t()
+                return
+            if theta < 0:
+                lo = theta
+            else:
+                hi = theta
+            theta = self.rng.uniform(lo, hi)
 
     # ---- node scores (GPU) ------------------------------------------------------------------------
     def score_u(self, uNoise=None, U=None):
+        if not self.nU:
+            return 0.0
         U = self.U if U is None else U
         un = self.v["uNoise"] if uNoise is None else uNoise
         return float(np.sum(api.mvnLogpdf(None, np.column_stack(U), covscale=np.full(self.nU, un), ctx=self.ctx)))
@@ -169,7 +236,7 @@ class _RealTChain:
 
     def score_x(self, v=None, U=None, only=None):
         """:X => k => :X for every covariate in ONE batched call (generateXfromU, src/model_likelihood.jl:13-22)."""
-        if not self.nX:
+        if not self.nX or not self.nU:    # NoU models: X ~ N(0, I), no hyper-parameters (src/model_prior.jl:175-181)
             return np.zeros(0)
         v = v or self.v
         ls = self._uxls_model(v)                                  # (nX, nU)
@@ -180,14 +247,16 @@ class _RealTChain:
 
     def score_t(self, v=None, U=None):   # generateRealTfromUX / fromU, src/model_likelihood.jl:36-44, 55-60
         v = v or self.v
-        F = self._umodel(U) if not self.nX else np.column_stack([self._umodel(U), self.X])
-        ls = v["utLS"] if not self.nX else np.concatenate([v["utLS"], v["xtLS"]])
-        return float(api.gpLogpdf(F, ls, v["tScale"], v["tNoise"], self.T, ctx=self.ctx)[0])
+        F, ls = self._t_features(U, v)
+        target = self.logitT if self.binary else self.T      # :logitT for binary treatments, :T otherwise
+        if not F.shape[1]:                # generateRealTfromPrior / BinaryTfromPrior: N(0, I), src/model_prior.jl:187-200
+            return float(-0.5 * (target @ target) - 0.5 * self.n * math.log(2.0 * math.pi))
+        return float(api.gpLogpdf(F, ls, v["tScale"], v["tNoise"], target, ctx=self.ctx)[0])
 
     def score_y(self, v=None, U=None):   # generateYfromUXT / UT, src/model_likelihood.jl:83-101
         v = v or self.v
-        cols = [self._umodel(U)] + ([self.X] if self.nX else []) + [self.T]
-        ls = np.concatenate([v["uyLS"]] + ([v["xyLS"]] if self.nX else []) + [[v["tyLS"]]])
+        cols = ([self._umodel(U)] if self.nU else []) + ([self.X] if self.nX else []) + [self.T]
+        ls = np.concatenate(([v["uyLS"]] if self.nU else []) + ([v["xyLS"]] if self.nX else []) + [[v["tyLS"]]])
         return float(api.gpLogpdf(np.column_stack(cols), ls, v["yScale"], v["yNoise"], self.Y, ctx=self.ctx)[0])
 
     # which node an address touches
@@ -272,19 +341,30 @@ class _RealTChain:
         # bracket collapsed onto the current state: keep it
 
     def sweep_mh(self):
-        """One inner sweep in the reference's address order (src/inference.jl:23-44 / :78-89)."""
-        self.mh("uNoise"); self.mh("tNoise"); self.mh("yNoise"); self.mh("tyLS")        # noqa: E702
+        """One inner sweep in the reference's address order (src/inference.jl:23-44 / :78-89 with U,
+        :126-139 / :324-337 NoU with covariates, :158-160 / :372-374 NoU NoCov)."""
+        if not self.nU and not self.nX:
+            self.mh("yNoise"); self.mh("tyLS"); self.mh("yScale")                       # noqa: E702
+            return
+        if self.nU:
+            self.mh("uNoise")
+        self.mh("tNoise"); self.mh("yNoise"); self.mh("tyLS")                           # noqa: E702
         for k in range(self.nU):
             self.mh("utLS", k); self.mh("uyLS", k)                                      # noqa: E702
             for l in range(self.nX):
                 self.mh("uxLS", k, l)
         for k in range(self.nX):
-            self.mh("xNoise", k); self.mh("xtLS", k); self.mh("xyLS", k); self.mh("xScale", k)   # noqa: E702
+            if self.nU:
+                self.mh("xNoise", k); self.mh("xtLS", k); self.mh("xyLS", k); self.mh("xScale", k)   # noqa: E702
+            else:
+                self.mh("xtLS", k); self.mh("xyLS", k)                                  # noqa: E702
         self.mh("tScale"); self.mh("yScale")                                            # noqa: E702
 
     def snapshot(self):
         out = {k: (val.copy() if isinstance(val, np.ndarray) else val) for k, val in self.v.items()}
         out["U"] = [u.copy() for u in self.U]
+        if self.binary:
+            out["logitT"] = self.logitT.copy()
         return out
 
 
@@ -292,20 +372,23 @@ def Posterior(priorparams, X, T, Y, nU, nOuter, nMHInner, nESInner, seed=1234, d
     """Posterior(priorparams, X or nothing, T::ContinuousTreatment, Y, nU, nOuter, nMHInner, nESInner)
     (src/inference.jl:4-59 with covariates, :62-102 without).  Returns the list of nOuter posterior samples
     (dicts keyed like the trace)."""
-    if nU is None or priorparams.get("SigmaU") is None or np.asarray(T).dtype == np.bool_:
-        raise NotImplementedError("built so far: the continuous-treatment models with latent confounders "
-                                  "(CausalGPSLCRealT, CausalGPSLCNoCovRealT); no-U and binary-treatment variants "
-                                  "are not — see DESIGN.md")
+    if nU is not None and priorparams.get("SigmaU") is None:
+        raise TypeError("nU given but priorparams['SigmaU'] is nothing: no matching Posterior method "
+                        "(pass HyperParameters(nU=None) for data without object labels)")
     rng = np.random.Generator(np.random.Philox(seed))
     Xa = None if X is None else np.asarray(X, float).reshape(len(Y), -1)
-    ch = _RealTChain(priorparams, priorparams["SigmaU"], Xa, np.asarray(T, float), np.asarray(Y, float), nU, rng,
-                     device=device)
+    binary = np.asarray(T).dtype == np.bool_
+    ch = _RealTChain(priorparams, priorparams["SigmaU"], Xa, np.asarray(T), np.asarray(Y, float), nU, rng,
+                     device=device, binary=binary)
     samples = []
+    no_u_no_cov = nU is None and Xa is None           # one MH sweep per outer iteration, no slice (:157-163, :371-377)
     for _ in range(nOuter):
-        for _ in range(nMHInner):
+        for _ in range(1 if no_u_no_cov else nMHInner):
             ch.sweep_mh()
-        for _ in range(nESInner):
-            for k in range(nU):
+        for _ in range(0 if no_u_no_cov else nESInner):
+            if binary:
+                ch.elliptical_slice_logitT()          # src/inference.jl:232, :348
+            for k in range(nU or 0):
                 ch.elliptical_slice(k)
         samples.append(ch.snapshot())
     return samples
@@ -320,16 +403,22 @@ def gpslc(data, hyperparams: Optional[HyperParameters] = None, priorparams: Opti
     pp = dict(priorparams or getPriorParameters())
     SigmaU, obj, X, T, Y = prepareData(data, pp["sigmaUNoise"], pp["sigmaUCov"])
     pp["SigmaU"] = SigmaU                                   # src/driver.jl:61
-    post = Posterior(pp, X, T, Y, hp.nU if SigmaU is not None else None, hp.nOuter, hp.nMHInner, hp.nESInner,
-                     seed=seed, device=device)
+    nU = hp.nU if SigmaU is not None else None
+    if SigmaU is None:                                      # GPSLCObject constructors, src/types.jl:277-289
+        import dataclasses
+        hp = dataclasses.replace(hp, nU=None)
+    post = Posterior(pp, X, T, Y, nU, hp.nOuter, hp.nMHInner, hp.nESInner, seed=seed, device=device)
     keep = post[hp.nBurnIn - 1:hp.nOuter:hp.stepSize]
-    S, n, nU = len(keep), len(Y), hp.nU
-    U = np.zeros((n, nU, S), order="F")
-    for s, smp in enumerate(keep):
-        for u in range(nU):
-            U[:, u, s] = smp["U"][u]                        # extractParameters: no interleave (src/utils.jl:103-106)
+    S, n = len(keep), len(Y)
+    U = uyLS = None
+    if nU:
+        U = np.zeros((n, nU, S), order="F")
+        for s, smp in enumerate(keep):
+            for u in range(nU):
+                U[:, u, s] = smp["U"][u]                    # extractParameters: no interleave (src/utils.jl:103-106)
+        uyLS = np.column_stack([smp["uyLS"] for smp in keep])
     xyLS = None if X is None else np.column_stack([smp["xyLS"] for smp in keep])
-    g = GPSLCObject(X, T, Y, U, np.column_stack([smp["uyLS"] for smp in keep]), xyLS,
+    g = GPSLCObject(X, np.asarray(T, dtype=np.float64), Y, U, uyLS, xyLS,
                     np.array([smp["tyLS"] for smp in keep]), np.array([smp["yNoise"] for smp in keep]),
                     np.array([smp["yScale"] for smp in keep]), hyperparams=hp, device=device)
     g.posteriorSamples = post

@@ -107,3 +107,72 @@ def test_full_model_chain_scores_are_consistent(gp):
     # model-side reshape of uxLS (src/model_prior.jl:110): nU traced vectors of length nX -> (nX, nU), interleaved
     v = {"uxLS": np.array([[1.0, 2.0, 3.0], [10.0, 20.0, 30.0]])}
     assert np.array_equal(ch._uxls_model(v), np.array([[1.0, 20.0], [10.0, 3.0], [2.0, 30.0]]))
+
+
+def test_binary_treatment_model_on_ihdp(gp):
+    """CausalGPSLCBinaryT (src/model.jl:73-89; chain src/inference.jl:169-242): :logitT slice + Bernoulli nodes,
+    on the reference's IHDP sample (272 rows, 6 covariates, binary T, 200 objects)."""
+    from causalgpslc_jl_amd import inference as inf
+    path = os.path.join(GOLD, "IHDP_sampled.csv")
+    SigmaU, obj, X, T, Y = gp.prepareData(path, 1e-6)
+    assert T.dtype == np.bool_ and X.shape == (272, 6) and len(set(obj)) == 200
+    pp = gp.getPriorParameters()
+    pp["SigmaU"] = SigmaU
+    ch = inf._RealTChain(pp, SigmaU, X, T, Y, 1, np.random.Generator(np.random.Philox(2)), binary=True)
+    l0 = ch.logitT.copy()
+    for _ in range(2):
+        ch.sweep_mh()
+        ch.elliptical_slice_logitT()
+        ch.elliptical_slice(0)
+    assert not np.array_equal(l0, ch.logitT)
+    assert np.isclose(ch.s_t, ch.score_t(), rtol=1e-12) and np.isclose(ch.s_b, ch.score_b(), rtol=1e-12)
+    # Bernoulli score against the direct formula
+    p = 1.0 / (1.0 + np.exp(-ch.logitT))
+    assert np.isclose(ch.s_b, np.sum(np.where(T, np.log(p), np.log1p(-p))), rtol=1e-10)
+    # host-side logitTCov used for the slice equals the covariance the GPU node scores with
+    import gpslc_oracle as orc
+    F, ls = ch._t_features()
+    ref = orc.process_cov(orc.rbf_kernel_log(F, F, ls), ch.v["tScale"], ch.v["tNoise"])
+    assert np.allclose(ch._t_cov(), ref, rtol=1e-9, atol=1e-12)
+    assert np.isclose(ch.s_t, orc.mvnormal_logpdf(ch.logitT, ref), rtol=1e-9)
+    hp = gp.HyperParameters(nU=1, nOuter=5, nMHInner=2, nESInner=2, nBurnIn=3)
+    g = gp.gpslc(path, hyperparams=hp, seed=4)
+    assert gp.getNumPosteriorSamples(g) == 3 and gp.getNX(g) == 6
+    ms, vs = gp.SATEDistributions(g, True)          # doT = true (src/types.jl:138-143: Bool interventions)
+    ms0, _ = gp.SATEDistributions(g, False)
+    assert np.all(np.isfinite(ms)) and np.all(vs > 0) and not np.allclose(ms, ms0)
+
+
+@pytest.mark.parametrize("csvname,nX", [("no_objects.csv", 1), ("no_objects_no_cov.csv", 0)])
+def test_gpslc_no_latent_confounders(gp, csvname, nX):
+    """test/gpslc.jl:14-21: inputs without object labels select the NoU models (src/types.jl:277-289 set
+    hyperparams.nU = nothing); prediction then runs without U (likelihoodDistribution methods 3 and 4)."""
+    path = os.path.join(GOLD, csvname)
+    hp = gp.HyperParameters(nOuter=5, nMHInner=1, nESInner=1, nBurnIn=2)
+    g = gp.gpslc(path, hyperparams=hp, seed=5)
+    assert g.SigmaU is None and g.U is None and g.hyperparams.nU is None
+    assert gp.getN(g) == 24 and gp.getNX(g) == nX and gp.getNU(g) == 0 and gp.getNumPosteriorSamples(g) == 4
+    assert np.all(np.isfinite(g.tyLS)) and np.all(g.yNoise > 0)
+    keys = set(g.posteriorSamples[0]) - {"U"}
+    assert keys == ({"yNoise", "tyLS", "yScale"} | ({"tNoise", "tScale", "xtLS", "xyLS"} if nX else set()))
+    # the chain moved at least one hyper-parameter
+    assert any(g.posteriorSamples[0][k] != g.posteriorSamples[-1][k] for k in ("yNoise", "tyLS", "yScale"))
+    ite = gp.sampleITE(g, 0.0, samplesPerPosterior=2, seed=1)
+    assert ite.shape == (24, 8) and np.all(np.isfinite(ite))
+    sate = gp.sampleSATE(g, 0.0, samplesPerPosterior=2, seed=1)
+    assert sate.shape == (8,) and np.all(np.isfinite(sate))
+
+
+def test_binary_treatment_without_objects(gp):
+    """CausalGPSLCNoUBinaryT (src/model.jl:91-106; chain src/inference.jl:304-354): IHDP columns without `obj`."""
+    import csv
+    with open(os.path.join(GOLD, "IHDP_sampled.csv")) as f:
+        rows = list(csv.DictReader(f))[:96]
+    cols = {k: [r[k] for r in rows] for k in rows[0] if k != "obj"}
+    hp = gp.HyperParameters(nOuter=4, nMHInner=1, nESInner=2, nBurnIn=2)
+    g = gp.gpslc(cols, hyperparams=hp, seed=6)
+    assert g.U is None and gp.getNX(g) == 6 and gp.getNumPosteriorSamples(g) == 3
+    l0, l1 = g.posteriorSamples[0]["logitT"], g.posteriorSamples[-1]["logitT"]
+    assert l0.shape == (96,) and not np.array_equal(l0, l1)
+    ms, vs = gp.SATEDistributions(g, True)
+    assert np.all(np.isfinite(ms)) and np.all(vs > 0)
