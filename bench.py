@@ -92,7 +92,10 @@ def main():
     rehearsal = os.environ.get("GPSLC_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if world > 1:
+    # GPSLC_BENCH_FORCE_DIST=1: run the collective path (RCCL init, all_gather, barrier, all_reduce) even with a
+    # single rank — the way to exercise the real "nccl" calls on a one-GPU box (under torch.distributed.run)
+    use_dist = world > 1 or os.environ.get("GPSLC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -127,15 +130,15 @@ def main():
     ctx.check(ctx.lib.gpslc_set_data_dev(ctx.h, ptr(dX), ptr(dT), ptr(dY)))
     ctx.set_tuning(a.max_batch, a.panel, a.streams)
 
-    gathered_m = [torch.empty_like(mS) for _ in range(world)] if world > 1 else None
-    gathered_v = [torch.empty_like(vS) for _ in range(world)] if world > 1 else None
+    gathered_m = [torch.empty_like(mS) for _ in range(world)] if use_dist else None
+    gathered_v = [torch.empty_like(vS) for _ in range(world)] if use_dist else None
 
     def step():
         st = ctx.lib.gpslc_predict_dev(ctx.h, Sr, ptr(dU), ptr(duy), ptr(dxy), ptr(dty), ptr(dys), ptr(dyn), L,
                                        ptr(ddo), 1e-10, 0, 0, None, ptr(mS), ptr(vS), ptr(mI), None)
         if not (st > 0 and os.environ.get("GPSLC_GEMM_DIAG")):   # diagnostic kernels produce garbage (non-PD)
             ctx.check(st)
-        if world > 1:   # the single end-of-step collective: SATE summaries of every rank's shard
+        if use_dist:   # the single end-of-step collective: SATE summaries of every rank's shard
             if rehearsal:   # gloo: gather through host memory
                 gm = [torch.empty(Sr * L, dtype=torch.float64) for _ in range(world)]
                 dist.all_gather(gm, mS.cpu())
@@ -146,7 +149,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,7 +162,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -205,7 +208,9 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, D, K, a.cpu_units, X, T, Y, post, float(doT[0]))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        if rank == 0 and not rehearsal:   # the gathered shards are what a caller would consume: check rank 0's own
+            assert torch.equal(gathered_m[0], mS) and torch.equal(gathered_v[0], vS)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -87,20 +87,21 @@ void launch_backsolve(const BackArgs& a, int nbatch, hipStream_t st) {
 // D = Ks' - K formed element-wise so that doT == T gives exact zeros, test/estimation.jl:6-66).
 // One workgroup per (row block, sample); levels are processed LC at a time.
 // ---------------------------------------------------------------------------------------
-template <int FREG, int LCT, typename RT>
+template <int FREG, int LCT, typename RT, int RB>
 __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
+    // RB row blocks per workgroup: every broadcast LDS read of a column's features / r / alpha serves RB
+    // rows of the same thread (the LDS pipe, not the fp64 VALU, bounded the RB = 1 form)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = a.nU + a.nX;
     double* al = sm;                       // [128]
     double* rl = al + GP_TS;               // [LCT][128]
-    double* red = rl + LCT * GP_TS;        // [128][LCT]
-    RT* fc = reinterpret_cast<RT*>(red + GP_TS * LCT);   // [FREG][128] column features / LS (zero rows beyond F)
+    double* red = rl + LCT * GP_TS;        // [RB][128][LCT]
+    RT* fc = reinterpret_cast<RT*>(red + RB * GP_TS * LCT);   // [FREG][128] column features / LS (zero rows beyond F)
     RT* tcs = fc + FREG * GP_TS;           // [128]
     const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;
     const int ib = blockIdx.x;
     const long long b = blockIdx.y, s = a.s0 + b;
     const int n = a.n, Np = a.nt * GP_TS;
-    const int gi = ib * GP_TS + r;
 
     auto feat_src = [&](int f) -> const double* {
         return (f < a.nU) ? a.p.U + s * a.p.u_sstride + (long long)f * n : a.X + (long long)(f - a.nU) * n;
@@ -108,22 +109,30 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     auto feat_il = [&](int f) -> double {
         return 1.0 / ((f < a.nU) ? a.p.uyLS[s * a.nU + f] : a.p.xyLS[s * a.nX + (f - a.nU)]);
     };
-    RT af[FREG];   // this thread's row features / LS
+    int gi[RB];
+    RT af[RB][FREG];   // this thread's rows' features / LS
+    RT tri[RB];
 #pragma unroll
-    for (int f = 0; f < FREG; ++f) af[f] = (RT)((f < F && gi < n) ? feat_src(f)[gi] * feat_il(f) : 0.0);
+    for (int q = 0; q < RB; ++q) {
+        gi[q] = (ib * RB + q) * GP_TS + r;
+#pragma unroll
+        for (int f = 0; f < FREG; ++f) af[q][f] = (RT)((f < F && gi[q] < n) ? feat_src(f)[gi[q]] * feat_il(f) : 0.0);
+        tri[q] = (RT)((gi[q] < n) ? a.T[gi[q]] : 0.0);
+    }
     const double ys = a.p.yScale[s];
     const double tl = a.p.tyLS[s];
     const double wt = 1.0 / (tl * tl);
     const RT wtq = (RT)wt;
     const RT ewq = RbfMath<RT>::exp_neg(-wtq);
-    const RT tri = (RT)((gi < n) ? a.T[gi] : 0.0);
     const double* alpha = a.alpha + b * Np;
 
     for (int l0 = 0; l0 < a.L; l0 += LCT) {
         const int nl = min(LCT, a.L - l0);
-        double acc[LCT];
+        double acc[RB][LCT];
 #pragma unroll
-        for (int ll = 0; ll < LCT; ++ll) acc[ll] = 0.0;
+        for (int q = 0; q < RB; ++q)
+#pragma unroll
+            for (int ll = 0; ll < LCT; ++ll) acc[q][ll] = 0.0;
         for (int jt = 0; jt < a.nt; ++jt) {
             __syncthreads();
             for (int idx = tid; idx < FREG * GP_TS; idx += 256) {
@@ -150,32 +159,47 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
 #pragma unroll 2
             for (int cq = 0; cq < 64; ++cq) {
                 const int c = h * 64 + cq;
-                RT lux = (RT)0;
+                RT cf[FREG];
 #pragma unroll
-                for (int f = 0; f < FREG; ++f) {
-                    const RT d = af[f] - fc[f * GP_TS + c];
-                    lux = fma(d, d, lux);
+                for (int f = 0; f < FREG; ++f) cf[f] = fc[f * GP_TS + c];
+                const RT tc = tcs[c];
+                const double alc = al[c];
+                double rlc[LCT];
+#pragma unroll
+                for (int ll = 0; ll < LCT; ++ll) rlc[ll] = rl[ll * GP_TS + c];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    RT lux = (RT)0;
+#pragma unroll
+                    for (int f = 0; f < FREG; ++f) {
+                        const RT d = af[q][f] - cf[f];
+                        lux = fma(d, d, lux);
+                    }
+                    const RT dt = tri[q] - tc;
+                    const double Bv = (double)((RT)ys * RbfMath<RT>::exp_neg(-lux));
+                    const double Ev = (double)(a.binary_t ? (dt == (RT)0 ? (RT)1 : ewq) : RbfMath<RT>::exp_neg(-((dt * dt) * wtq)));
+                    const double ba = Bv * alc;
+#pragma unroll
+                    for (int ll = 0; ll < LCT; ++ll) acc[q][ll] = fma(ba, rlc[ll] - Ev, acc[q][ll]);
                 }
-                const RT dt = tri - tcs[c];
-                const double Bv = (double)((RT)ys * RbfMath<RT>::exp_neg(-lux));
-                const double Ev = (double)(a.binary_t ? (dt == (RT)0 ? (RT)1 : ewq) : RbfMath<RT>::exp_neg(-((dt * dt) * wtq)));
-                const double ba = Bv * al[c];
-#pragma unroll
-                for (int ll = 0; ll < LCT; ++ll) acc[ll] = fma(ba, rl[ll * GP_TS + c] - Ev, acc[ll]);
             }
         }
         __syncthreads();
         if (h == 1) {
 #pragma unroll
-            for (int ll = 0; ll < LCT; ++ll) red[r * LCT + ll] = acc[ll];
+            for (int q = 0; q < RB; ++q)
+#pragma unroll
+                for (int ll = 0; ll < LCT; ++ll) red[(q * GP_TS + r) * LCT + ll] = acc[q][ll];
         }
         __syncthreads();
-        if (h == 0 && gi < n) {
+        if (h == 0) {
 #pragma unroll
-            for (int ll = 0; ll < LCT; ++ll)
-                if (ll < nl)
-                    a.meanITE[(long long)gi * a.si + s * a.ss + (long long)(l0 + ll) * a.sl] =
-                        acc[ll] + red[r * LCT + ll];
+            for (int q = 0; q < RB; ++q)
+#pragma unroll
+                for (int ll = 0; ll < LCT; ++ll)
+                    if (ll < nl && gi[q] < n)
+                        a.meanITE[(long long)gi[q] * a.si + s * a.ss + (long long)(l0 + ll) * a.sl] =
+                            acc[q][ll] + red[(q * GP_TS + r) * LCT + ll];
         }
     }
 }
@@ -364,14 +388,15 @@ static void launch_ite_mean_mfma(const IteMeanArgs& a, int nbatch, hipStream_t s
 
 template <int FREG, int LCT, typename RT>
 static void launch_ite_mean_t(const IteMeanArgs& a, int nbatch, hipStream_t st) {
-    const int bytes = (GP_TS + 2 * LCT * GP_TS) * 8 + (FREG * GP_TS + GP_TS) * (int)sizeof(RT);
+    constexpr int RB = 1;     // row blocks per workgroup (register budget)
+    const int bytes = (GP_TS + (1 + RB) * LCT * GP_TS) * 8 + (FREG * GP_TS + GP_TS) * (int)sizeof(RT);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ite_mean_kernel<FREG, LCT, RT>,
+        (void)hipFuncSetAttribute((const void*)ite_mean_kernel<FREG, LCT, RT, RB>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((ite_mean_kernel<FREG, LCT, RT>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
+    hipLaunchKernelGGL((ite_mean_kernel<FREG, LCT, RT, RB>), dim3((a.nt + RB - 1) / RB, nbatch), dim3(256), bytes, st, a);
 }
 template <int FREG, typename RT>
 static void launch_ite_mean_f(const IteMeanArgs& a, int nbatch, hipStream_t st) {

@@ -46,6 +46,33 @@ __global__ __launch_bounds__(256) void rate_kernel(double* out, int iters, doubl
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
+// sustained variant: operands with random mantissas (data-dependent switching power), launched back to back
+// for > 1 s so that the power manager settles — the ceiling a long-running MFMA kernel can actually hold
+__global__ __launch_bounds__(256) void rate_random_kernel(double* out, int iters, unsigned seed, unsigned long long* clk) {
+    d4 acc[8];
+    unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + seed;
+    auto rnd = [&h]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+                        const unsigned lo = h * 2246822519u;
+                        return __longlong_as_double(0x3FF0000000000000ll | ((long long)(h & 0xFFFFF) << 32) | lo) - 1.5; };
+    for (int i = 0; i < 8; ++i) acc[i] = (d4){rnd(), rnd(), rnd(), rnd()};
+    const double a = rnd(), b = rnd();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it += 32) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 1);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
 // plain vector FMA rate for comparison (spec: vector fp64 = matrix fp64 = 78.6 TF)
 __global__ __launch_bounds__(256) void valu_kernel(double* out, int iters, double seed, unsigned long long* clk) {
     double x[16];
@@ -112,6 +139,21 @@ int main() {
             printf("mfma_f64_16x16x4: %d CUs, %d wave/SIMD, 8 acc: %.2f ms  %.2f TFLOP/s  in-kernel clock %.2f GHz, %.1f cycles/MFMA/SIMD\n",
                    cus, wpc, ms, flop / (ms * 1e-3) / 1e12, ghz, cyc);
         }
+    }
+    {   // sustained: 150 back-to-back launches at 2 waves/SIMD, the last 100 timed
+        const int blocks = cus * 2, iters = 20480, total = 150, timed = 100;
+        for (int l = 0; l < total; ++l) {
+            if (l == total - timed) HC(hipEventRecord(e_a));
+            hipLaunchKernelGGL(rate_random_kernel, dim3(blocks), dim3(256), 0, 0, dout, iters, 17u + l, dclk);
+        }
+        HC(hipEventRecord(e_b));
+        HC(hipEventSynchronize(e_b));
+        float ms; HC(hipEventElapsedTime(&ms, e_a, e_b));
+        HC(hipMemcpy(hclk, dclk, 16, hipMemcpyDeviceToHost));
+        const double flop = (double)timed * blocks * 4 * iters * 8 * 2.0 * 16 * 16 * 4;
+        printf("mfma_f64_16x16x4 SUSTAINED (random operands, alternating NEG, %d launches = %.0f ms timed): %.2f TFLOP/s  "
+               "in-kernel clock %.2f GHz (last launch)\n", timed, ms, flop / (ms * 1e-3) / 1e12,
+               (double)hclk[0] / (double)hclk[1] * 0.1);
     }
     for (int sub = 0; sub < 2; ++sub) {   // a subset of the CUs: is the rate chip-power limited?
         const int blocks = sub == 0 ? 32 : 128;
