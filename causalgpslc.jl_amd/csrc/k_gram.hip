@@ -26,7 +26,8 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /* >= 4 do
 // Gram build: one workgroup per lower tile (ti >= tj) per posterior sample.
 // Thread (tx = tid>>4, ty = tid&15) owns rows ty + 16p and columns 8 tx + q, p, q = 0..7.
 // ---------------------------------------------------------------------------------------
-template <typename RT>
+template <typename RT, int BIN>   // BIN: binary treatments (e_ij is 1 or exp(-1/tyLS^2)); a template parameter so that the
+                                  // 16 exp chains of a column are branch-free and interleave
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = g.nU + g.nX;
@@ -111,13 +112,12 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
             const int gi = gi0 + rp;
             const RT dt = tra[p] - tcq;
             const RT Bq = (RT)ys * RbfMath<RT>::exp_neg(-lux[p]);
-            const RT Eq = g.binary_t ? (dt == (RT)0 ? (RT)1 : ew) : RbfMath<RT>::exp_neg(-((dt * dt) * wt));
-            double Bv = (double)Bq;
-            double Kv = (double)(Bq * Eq);
-            double Av = Kv;
+            const RT Eq = BIN ? (dt == (RT)0 ? (RT)1 : ew) : RbfMath<RT>::exp_neg(-((dt * dt) * wt));
             const bool inside = (gi < n) && (gj < n);
-            if (!inside) { Bv = 0.0; Kv = 0.0; Av = (gi == gj) ? 1.0 : 0.0; }
-            else if (gi == gj) Av = Kv + yn;
+            const double Bv = inside ? (double)Bq : 0.0;
+            const double Kv = inside ? (double)(Bq * Eq) : 0.0;
+            // diagonal: + yNoise inside, identity on the padding
+            const double Av = (gi == gj) ? (inside ? Kv + yn : 1.0) : Kv;
             tile[cq * GP_TS + rp] = Av;
             rsB[p] += Bv; rsK[p] += Kv;
             csB += Bv; csK += Kv;
@@ -164,19 +164,27 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
 void launch_gram(const GramArgs& g, int nbatch, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gram_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)gram_kernel<double, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   GRAM_LDS_BYTES(MAXF, 8));
-        (void)hipFuncSetAttribute((const void*)gram_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)gram_kernel<double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GRAM_LDS_BYTES(MAXF, 8));
+        (void)hipFuncSetAttribute((const void*)gram_kernel<float, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GRAM_LDS_BYTES(MAXF, 4));
+        (void)hipFuncSetAttribute((const void*)gram_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   GRAM_LDS_BYTES(MAXF, 4));
         attr_set = true;
     }
     // one workgroup per (tile, sample): a persistent variant measured 0.7 % slower (same-box A/B)
     const int nlow = g.nt * (g.nt + 1) / 2;
     const int F = g.nU + g.nX;
-    if (g.f32)
-        hipLaunchKernelGGL(gram_kernel<float>, dim3(nlow, nbatch), dim3(256), GRAM_LDS_BYTES(F, 4), st, g);
-    else
-        hipLaunchKernelGGL(gram_kernel<double>, dim3(nlow, nbatch), dim3(256), GRAM_LDS_BYTES(F, 8), st, g);
+    const dim3 grid(nlow, nbatch);
+    if (g.f32) {
+        if (g.binary_t) hipLaunchKernelGGL((gram_kernel<float, 1>), grid, dim3(256), GRAM_LDS_BYTES(F, 4), st, g);
+        else hipLaunchKernelGGL((gram_kernel<float, 0>), grid, dim3(256), GRAM_LDS_BYTES(F, 4), st, g);
+    } else {
+        if (g.binary_t) hipLaunchKernelGGL((gram_kernel<double, 1>), grid, dim3(256), GRAM_LDS_BYTES(F, 8), st, g);
+        else hipLaunchKernelGGL((gram_kernel<double, 0>), grid, dim3(256), GRAM_LDS_BYTES(F, 8), st, g);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

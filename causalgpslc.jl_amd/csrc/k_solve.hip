@@ -87,7 +87,7 @@ void launch_backsolve(const BackArgs& a, int nbatch, hipStream_t st) {
 // D = Ks' - K formed element-wise so that doT == T gives exact zeros, test/estimation.jl:6-66).
 // One workgroup per (row block, sample); levels are processed LC at a time.
 // ---------------------------------------------------------------------------------------
-template <int FREG, int LCT, typename RT, int RB>
+template <int FREG, int LCT, typename RT, int RB, int BIN>
 __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     // RB row blocks per workgroup: every broadcast LDS read of a column's features / r / alpha serves RB
     // rows of the same thread (the LDS pipe, not the fp64 VALU, bounded the RB = 1 form)
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
                     }
                     const RT dt = tri[q] - tc;
                     const double Bv = (double)((RT)ys * RbfMath<RT>::exp_neg(-lux));
-                    const double Ev = (double)(a.binary_t ? (dt == (RT)0 ? (RT)1 : ewq) : RbfMath<RT>::exp_neg(-((dt * dt) * wtq)));
+                    const double Ev = (double)(BIN ? (dt == (RT)0 ? (RT)1 : ewq) : RbfMath<RT>::exp_neg(-((dt * dt) * wtq)));
                     const double ba = Bv * alc;
 #pragma unroll
                     for (int ll = 0; ll < LCT; ++ll) acc[q][ll] = fma(ba, rlc[ll] - Ev, acc[q][ll]);
@@ -222,7 +222,7 @@ typedef double d4s __attribute__((ext_vector_type(4)));
 #define IM_RLD 80         // padded row of the R chunk (doubles): conflict-free ds_read_b64 across k rows
 #define IM_NL 64          // levels per pass
 
-template <int FREG>   // FREG > 0: this lane's two rows' features live in registers (F <= FREG); 0: read from LDS
+template <int FREG, int BIN>   // FREG > 0: this lane's two rows' features live in registers (F <= FREG); 0: read from LDS
 __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = a.nU + a.nX;
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
                 const double tc = tcs[cc];
                 const double dt0 = t0 - tc, dt1 = t1 - tc;
                 const double B0 = ys * gp_exp_neg(-lux0), B1 = ys * gp_exp_neg(-lux1);
-                const double E0 = a.binary_t ? (dt0 == 0.0 ? 1.0 : ew) : gp_exp_neg(-((dt0 * dt0) * wt));
-                const double E1 = a.binary_t ? (dt1 == 0.0 ? 1.0 : ew) : gp_exp_neg(-((dt1 * dt1) * wt));
+                const double E0 = BIN ? (dt0 == 0.0 ? 1.0 : ew) : gp_exp_neg(-((dt0 * dt0) * wt));
+                const double E1 = BIN ? (dt1 == 0.0 ? 1.0 : ew) : gp_exp_neg(-((dt1 * dt1) * wt));
                 const double K0 = B0 * E0, K1 = B1 * E1;
                 const double av = (li == 0) ? al[cc] : 0.0;       // alpha as a one-column right operand
                 const double* Rrow = R + cc * IM_RLD + li;
@@ -365,19 +365,24 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
     }
 }
 
-template <int FREG>
-static void launch_ite_mean_mfma_t(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+template <int FREG, int BIN>
+static void launch_ite_mean_mfma_tb(const IteMeanArgs& a, int nbatch, hipStream_t st) {
     const int F = a.nU + a.nX;
     const int FS = FREG > F ? FREG : F;
     const int bytes = (F * GP_TS + FS * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ite_mean_mfma_kernel<FREG>,
+        (void)hipFuncSetAttribute((const void*)ite_mean_mfma_kernel<FREG, BIN>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (MAXF * GP_TS + MAXF * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ite_mean_mfma_kernel<FREG>, dim3(a.nt, nbatch), dim3(256), bytes, st, a);
+    hipLaunchKernelGGL((ite_mean_mfma_kernel<FREG, BIN>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
+}
+template <int FREG>
+static void launch_ite_mean_mfma_t(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+    if (a.binary_t) launch_ite_mean_mfma_tb<FREG, 1>(a, nbatch, st);
+    else launch_ite_mean_mfma_tb<FREG, 0>(a, nbatch, st);
 }
 static void launch_ite_mean_mfma(const IteMeanArgs& a, int nbatch, hipStream_t st) {
     const int F = a.nU + a.nX;
@@ -386,17 +391,23 @@ static void launch_ite_mean_mfma(const IteMeanArgs& a, int nbatch, hipStream_t s
     else launch_ite_mean_mfma_t<0>(a, nbatch, st);
 }
 
-template <int FREG, int LCT, typename RT>
-static void launch_ite_mean_t(const IteMeanArgs& a, int nbatch, hipStream_t st) {
-    constexpr int RB = 1;     // row blocks per workgroup (register budget)
+template <int FREG, int LCT, typename RT, int BIN>
+static void launch_ite_mean_tb(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+    constexpr int RB = 1;     // row blocks per workgroup (2 measured slower: occupancy)
     const int bytes = (GP_TS + (1 + RB) * LCT * GP_TS) * 8 + (FREG * GP_TS + GP_TS) * (int)sizeof(RT);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ite_mean_kernel<FREG, LCT, RT, RB>,
+        (void)hipFuncSetAttribute((const void*)ite_mean_kernel<FREG, LCT, RT, RB, BIN>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((ite_mean_kernel<FREG, LCT, RT, RB>), dim3((a.nt + RB - 1) / RB, nbatch), dim3(256), bytes, st, a);
+    hipLaunchKernelGGL((ite_mean_kernel<FREG, LCT, RT, RB, BIN>), dim3((a.nt + RB - 1) / RB, nbatch), dim3(256), bytes, st, a);
+}
+template <int FREG, int LCT, typename RT>
+static void launch_ite_mean_t(const IteMeanArgs& a, int nbatch, hipStream_t st) {
+    // binary treatments as a template parameter: a runtime flag puts the exp behind a branch in the hot loop
+    if (a.binary_t) launch_ite_mean_tb<FREG, LCT, RT, 1>(a, nbatch, st);
+    else launch_ite_mean_tb<FREG, LCT, RT, 0>(a, nbatch, st);
 }
 template <int FREG, typename RT>
 static void launch_ite_mean_f(const IteMeanArgs& a, int nbatch, hipStream_t st) {
@@ -407,8 +418,14 @@ static void launch_ite_mean_f(const IteMeanArgs& a, int nbatch, hipStream_t st) 
 template <typename RT>
 static void launch_ite_mean_r(const IteMeanArgs& a, int nbatch, hipStream_t st) {
     const int F = a.nU + a.nX;
+    // exact register counts for the common feature widths: the pass is fp64-VALU bound (2 instructions per
+    // feature per element), a padded feature is paid in full
     if (F <= 4) launch_ite_mean_f<4, RT>(a, nbatch, st);
+    else if (F <= 6) launch_ite_mean_f<6, RT>(a, nbatch, st);
+    else if (F <= 8) launch_ite_mean_f<8, RT>(a, nbatch, st);
+    else if (F <= 10) launch_ite_mean_f<10, RT>(a, nbatch, st);
     else if (F <= 12) launch_ite_mean_f<12, RT>(a, nbatch, st);
+    else if (F <= 16) launch_ite_mean_f<16, RT>(a, nbatch, st);
     else if (F <= 20) launch_ite_mean_f<20, RT>(a, nbatch, st);
     else launch_ite_mean_f<32, RT>(a, nbatch, st);
 }
