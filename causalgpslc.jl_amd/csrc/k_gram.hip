@@ -9,6 +9,7 @@
 //   rbf_log / process_cov  the two src/kernel.jl entry points as stand-alone dense kernels.
 #include "gpslc_internal.h"
 #include "gp_math.h"
+#include <type_traits>
 
 #define MAXF 32   // max nU + nX handled by the fused Gram kernel
 
@@ -26,11 +27,11 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /* >= 4 do
 // Gram build: one workgroup per lower tile (ti >= tj) per posterior sample.
 // Thread (tx = tid>>4, ty = tid&15) owns rows ty + 16p and columns 8 tx + q, p, q = 0..7.
 // ---------------------------------------------------------------------------------------
-template <typename RT, int BIN>   // BIN: binary treatments (e_ij is 1 or exp(-1/tyLS^2)); a template parameter so that the
+template <typename RT, int BIN, int FT>   // FT: exact feature count (0 = runtime): the distance loop unrolls fully.  BIN: binary treatments (e_ij is 1 or exp(-1/tyLS^2)); a template parameter so that the
                                   // 16 exp chains of a column are branch-free and interleave
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int F = g.nU + g.nX;
+    const int F = FT > 0 ? FT : g.nU + g.nX;
     double* red = sm;                    // [4][128][2] cross-wave row-sum staging
     RT* fr = reinterpret_cast<RT*>(red + 4 * GP_TS * 2);   // [F][128] row-block features / LS
     RT* fc = fr + F * GP_TS;             // [F][128] column-block features / LS
@@ -89,49 +90,63 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
 
     // runtime loop over this thread's 8 columns keeps the (inlined) exp code small enough for the
     // instruction cache; the row features are re-read from LDS per column (cheap next to 16 exps)
+    // interior off-diagonal tiles (all but nt + a few of the nt(nt+1)/2) need no padding / diagonal selects:
+    // v_cndmask issues at a quarter of the v_fma_f64 rate (tools/valu_rate_bench), 8.5 of them per element
+    // cost as much as a third of the arithmetic
+    auto columns = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll 1
-    for (int q = 0; q < 8; ++q) {
-        const int cq = 8 * tx + q;
-        const int gj = gj0 + cq;
-        RT lux[8];
+        for (int q = 0; q < 8; ++q) {
+            const int cq = 8 * tx + q;
+            const int gj = gj0 + cq;
+            RT lux[8];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) lux[p] = (RT)0;
-        for (int f = 0; f < F; ++f) {
-            const RT c = fc[f * GP_TS + cq];
+            for (int p = 0; p < 8; ++p) lux[p] = (RT)0;
+#pragma unroll 2
+            for (int f = 0; f < (FT > 0 ? FT : F); ++f) {
+                const RT c = fc[f * GP_TS + cq];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const RT d = fr[f * GP_TS + ty + 16 * p] - c;
+                    lux[p] = fma(d, d, lux[p]);
+                }
+            }
+            const RT tcq = tc[cq];
+            double csB = 0.0, csK = 0.0;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                const RT d = fr[f * GP_TS + ty + 16 * p] - c;
-                lux[p] = fma(d, d, lux[p]);
+                const int rp = ty + 16 * p;
+                const int gi = gi0 + rp;
+                const RT dt = tra[p] - tcq;
+                const RT Bq = (RT)ys * RbfMath<RT>::exp_neg(-lux[p]);
+                const RT Eq = BIN ? (dt == (RT)0 ? (RT)1 : ew) : RbfMath<RT>::exp_neg(-((dt * dt) * wt));
+                double Bv, Kv, Av;
+                if (FAST) {
+                    Bv = (double)Bq; Kv = (double)(Bq * Eq); Av = Kv;
+                } else {
+                    const bool inside = (gi < n) && (gj < n);
+                    Bv = inside ? (double)Bq : 0.0;
+                    Kv = inside ? (double)(Bq * Eq) : 0.0;
+                    // diagonal: + yNoise inside, identity on the padding
+                    Av = (gi == gj) ? (inside ? Kv + yn : 1.0) : Kv;
+                }
+                tile[cq * GP_TS + rp] = Av;
+                rsB[p] += Bv; rsK[p] += Kv;
+                csB += Bv; csK += Kv;
+            }
+            if (g.with_sums) {
+                // column sums: reduce over the 16 ty lanes (lane bits 0..3)
+#pragma unroll
+                for (int o = 1; o <= 8; o <<= 1) { csB += __shfl_xor(csB, o, 64); csK += __shfl_xor(csK, o, 64); }
+                if (ty == 0) {
+                    partB[(long long)ti * Np + gj] = csB;
+                    partK[(long long)ti * Np + gj] = csK;
+                }
             }
         }
-        const RT tcq = tc[cq];
-        double csB = 0.0, csK = 0.0;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int rp = ty + 16 * p;
-            const int gi = gi0 + rp;
-            const RT dt = tra[p] - tcq;
-            const RT Bq = (RT)ys * RbfMath<RT>::exp_neg(-lux[p]);
-            const RT Eq = BIN ? (dt == (RT)0 ? (RT)1 : ew) : RbfMath<RT>::exp_neg(-((dt * dt) * wt));
-            const bool inside = (gi < n) && (gj < n);
-            const double Bv = inside ? (double)Bq : 0.0;
-            const double Kv = inside ? (double)(Bq * Eq) : 0.0;
-            // diagonal: + yNoise inside, identity on the padding
-            const double Av = (gi == gj) ? (inside ? Kv + yn : 1.0) : Kv;
-            tile[cq * GP_TS + rp] = Av;
-            rsB[p] += Bv; rsK[p] += Kv;
-            csB += Bv; csK += Kv;
-        }
-        if (g.with_sums) {
-            // column sums: reduce over the 16 ty lanes (lane bits 0..3)
-#pragma unroll
-            for (int o = 1; o <= 8; o <<= 1) { csB += __shfl_xor(csB, o, 64); csK += __shfl_xor(csK, o, 64); }
-            if (ty == 0) {
-                partB[(long long)ti * Np + gj] = csB;
-                partK[(long long)ti * Np + gj] = csK;
-            }
-        }
-    }
+    };
+    if (ti != tj && gi0 + GP_TS <= n && gj0 + GP_TS <= n) columns(std::true_type{});
+    else columns(std::false_type{});
     // diagonal tile: the full square was computed, column sums are complete
     if (!g.with_sums || ti == tj) return;
 
@@ -161,30 +176,35 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
 
 #define GRAM_LDS_BYTES(F, RTS) (4 * GP_TS * 2 * 8 + (2 * (F) * GP_TS + 2 * GP_TS) * (RTS))
 
-void launch_gram(const GramArgs& g, int nbatch, hipStream_t st) {
+template <typename RT, int BIN, int FT>
+static void launch_gram_t(const GramArgs& g, int nbatch, hipStream_t st) {
+    const int F = g.nU + g.nX;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gram_kernel<double, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GRAM_LDS_BYTES(MAXF, 8));
-        (void)hipFuncSetAttribute((const void*)gram_kernel<double, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GRAM_LDS_BYTES(MAXF, 8));
-        (void)hipFuncSetAttribute((const void*)gram_kernel<float, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GRAM_LDS_BYTES(MAXF, 4));
-        (void)hipFuncSetAttribute((const void*)gram_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GRAM_LDS_BYTES(MAXF, 4));
+        (void)hipFuncSetAttribute((const void*)gram_kernel<RT, BIN, FT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  GRAM_LDS_BYTES(MAXF, (int)sizeof(RT)));
         attr_set = true;
     }
     // one workgroup per (tile, sample): a persistent variant measured 0.7 % slower (same-box A/B)
     const int nlow = g.nt * (g.nt + 1) / 2;
-    const int F = g.nU + g.nX;
-    const dim3 grid(nlow, nbatch);
-    if (g.f32) {
-        if (g.binary_t) hipLaunchKernelGGL((gram_kernel<float, 1>), grid, dim3(256), GRAM_LDS_BYTES(F, 4), st, g);
-        else hipLaunchKernelGGL((gram_kernel<float, 0>), grid, dim3(256), GRAM_LDS_BYTES(F, 4), st, g);
-    } else {
-        if (g.binary_t) hipLaunchKernelGGL((gram_kernel<double, 1>), grid, dim3(256), GRAM_LDS_BYTES(F, 8), st, g);
-        else hipLaunchKernelGGL((gram_kernel<double, 0>), grid, dim3(256), GRAM_LDS_BYTES(F, 8), st, g);
+    hipLaunchKernelGGL((gram_kernel<RT, BIN, FT>), dim3(nlow, nbatch), dim3(256), GRAM_LDS_BYTES(F, (int)sizeof(RT)), st, g);
+}
+template <typename RT, int BIN>
+static void launch_gram_b(const GramArgs& g, int nbatch, hipStream_t st) {
+    switch (g.nU + g.nX) {   // exact instantiations for the common feature counts
+        case 4: launch_gram_t<RT, BIN, 4>(g, nbatch, st); break;
+        case 5: launch_gram_t<RT, BIN, 5>(g, nbatch, st); break;
+        case 6: launch_gram_t<RT, BIN, 6>(g, nbatch, st); break;
+        case 8: launch_gram_t<RT, BIN, 8>(g, nbatch, st); break;
+        case 10: launch_gram_t<RT, BIN, 10>(g, nbatch, st); break;
+        case 12: launch_gram_t<RT, BIN, 12>(g, nbatch, st); break;
+        case 20: launch_gram_t<RT, BIN, 20>(g, nbatch, st); break;
+        default: launch_gram_t<RT, BIN, 0>(g, nbatch, st); break;
     }
+}
+void launch_gram(const GramArgs& g, int nbatch, hipStream_t st) {
+    if (g.f32) { if (g.binary_t) launch_gram_b<float, 1>(g, nbatch, st); else launch_gram_b<float, 0>(g, nbatch, st); }
+    else { if (g.binary_t) launch_gram_b<double, 1>(g, nbatch, st); else launch_gram_b<double, 0>(g, nbatch, st); }
 }
 
 // ---------------------------------------------------------------------------------------
