@@ -42,3 +42,35 @@ def test_random_shapes(gp, seed):
         for l in range(min(L, 3)):
             m, _ = orc.structured_ite(p, X, T, Y, doTs[l])
             assert np.max(np.abs(mi[:, s, l] - m)) <= 1e-9 * np.max(np.abs(m)) + 1e-13
+
+
+@pytest.mark.parametrize("nU,nX,L,binary", [(2, 10, 1, False), (3, 10, 4, True), (4, 12, 1, False), (4, 16, 9, False),
+                                            (5, 16, 2, True), (8, 24, 1, False), (8, 24, 6, True), (1, 4, 1, True),
+                                            (0, 5, 3, False), (2, 4, 1, False), (0, 8, 1, True)])
+def test_wide_feature_counts(gp, nU, nX, L, binary):
+    """Every feature-count instantiation of the Gram / MeanITE kernels (exact 4, 5, 6, 8, 10, 12, 20; register
+    classes 16, 20, 32; the runtime-count paths) up to the ABI's maximum nU + nX = 32."""
+    rng = np.random.default_rng(7 + 31 * nU + nX + L)
+    n, S = 150, 2
+    X = 0.3 * rng.standard_normal((n, nX))
+    T = (rng.random(n) < 0.5).astype(float) if binary else rng.standard_normal(n)
+    Y = rng.standard_normal(n)
+    ig = lambda size: np.maximum(4.0 / rng.gamma(4.0, 1.0, size=size), 0.5)   # noqa: E731
+    U = 0.3 * rng.standard_normal((n, nU, S)) if nU else None
+    uyLS = ig((nU, S)) if nU else None
+    xyLS = ig((nX, S))
+    tyLS, yNoise, yScale = ig(S), ig(S), ig(S)
+    doTs = rng.uniform(-1.0, 1.0, L)
+    if binary:
+        doTs[0] = 1.0
+    g = gp.GPSLCObject(X, T, Y, U, uyLS, xyLS, tyLS, yNoise, yScale)
+    ms, vs, mi = gp.predict(g, doTs, want_mean_ite=True)
+    for s in range(S):
+        p = orc.PosteriorSample(None if nU == 0 else uyLS[:, s], xyLS[:, s], float(tyLS[s]), float(yNoise[s]),
+                                float(yScale[s]), None if nU == 0 else U[:, :, s])
+        rm, rv, _, _ = orc.structured_sate(p, X, T, Y, doTs)
+        assert np.all(np.abs(ms[s] - rm) <= 1e-9 * np.abs(rm) + 1e-13)
+        assert np.all(np.abs(vs[s] - rv) <= 1e-8 * np.abs(rv) + 1e-12 * p.yScale)
+        for l in range(L):
+            m, _ = orc.structured_ite(p, X, T, Y, doTs[l])
+            assert np.max(np.abs(mi[:, s, l] - m)) <= 1e-9 * np.max(np.abs(m)) + 1e-13
