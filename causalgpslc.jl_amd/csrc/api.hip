@@ -62,6 +62,7 @@ struct gpslc_ctx {
     int nstreams = 1;   // chunks of one call alternate over this many HIP streams (2 buys ~1-2 %, see profiles/)
     std::vector<hipStream_t> streams;
     std::vector<Arena> arenas;     // one per stream slot
+    std::vector<int*> queues;      // one ticket-counter block (16 ints) per stream slot, see GemmArgs::queue
     Arena scratch;                 // call-level buffers (host-pointer entry points, info, ...)
     std::string err;
     std::vector<int32_t> last_info;
@@ -120,13 +121,30 @@ void ensure_streams(gpslc_ctx* c) {
         c->streams.push_back(s);
     }
     if ((int)c->arenas.size() < c->nstreams) c->arenas.resize(c->nstreams);
+    while ((int)c->queues.size() < c->nstreams) {
+        int* q = nullptr;
+        HC(hipMalloc((void**)&q, 16 * sizeof(int)));
+        HC(hipMemset(q, 0, 16 * sizeof(int)));
+        c->queues.push_back(q);
+    }
 }
 
 // ---- profiled launch of the accumulate-mode tile kernel ---------------------------------
+// GPSLC_SYRK_DIAG=0 keeps the diagonal tiles in the general kernel (A/B switch for measurements)
+static int sym_mode() {
+    static const int m = [] { const char* e = getenv("GPSLC_SYRK_DIAG"); return (e && atoi(e) == 0) ? 1 : 2; }();
+    return m;
+}
+
 void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
     static const int diag_skip = getenv("GPSLC_GEMM_DIAG") ? atoi(getenv("GPSLC_GEMM_DIAG")) : 0;
     g.diag_skip = diag_skip;   // timing-only diagnostic, results are garbage when set
+    static const int use_queue = getenv("GPSLC_GEMM_QUEUE") ? atoi(getenv("GPSLC_GEMM_QUEUE")) : 1;
+    g.queue = nullptr;
+    if (use_queue)
+        for (size_t i = 0; i < c->streams.size() && i < c->queues.size(); ++i)
+            if (c->streams[i] == st) g.queue = c->queues[i];
     static const int dbg_m = getenv("GPSLC_GEMM_DBG") ? atoi(getenv("GPSLC_GEMM_DBG")) : 0;
     static bool dbg_done = false;
     unsigned long long* dbg_buf = nullptr;
@@ -139,6 +157,15 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
         dbg_done = true;
     }
     if (g.ntiles <= 0 || g.nbatch <= 0 || (g.k1 <= g.k0 && g.accumulate)) return;
+    // sym == 2: the full-size diagonal tiles (those above the augmented rows) go to the lower-triangle kernel
+    auto launch_both = [&]() {
+        launch_tile_gemm(g, st);
+        if (g.sym == 2 && g.shape == 0 && g.diag_skip == 0) {
+            GemmArgs d = g;
+            d.mi = g.short_rows > 0 ? std::max(0, std::min(g.mi, g.short_row0 - g.i0)) : g.mi;
+            launch_syrk_diag(d, st);
+        }
+    };
     const bool prof = (c->flags & GPSLC_FLAG_PROFILE) && g.accumulate;
     if (prof) {
         if (c->prof_used == c->prof.size()) {
@@ -156,17 +183,20 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
             const int last = g.i0 + g.mi - 1;                       // last output tile row of the launch
             if (last >= g.short_row0) short_items = (g.shape == 0) ? (double)g.mi : (double)g.mj;
         }
-        // diagonal tiles of a symmetric (lower-triangle) launch need only their lower triangle: half a
-        // tile product, as in the textbook N^3/3 count (the kernel computes the whole tile)
-        const double diag_items = (g.shape == 0) ? (double)g.mi : 0.0;
+        // diagonal tiles of a symmetric launch need only their lower triangle: half a tile product, as in the
+        // textbook N^3/3 count (the kernel runs 36 of the 64 sub-tile products, GemmArgs::sym); the short
+        // augmented diagonal tile is already counted by its live rows
+        double diag_items = 0.0;
+        if (g.sym && g.i0 == g.j0) diag_items = (g.shape == 0) ? (double)g.mi : 1.0;
+        if (short_items > 0 && g.shape == 0) diag_items -= 1.0;
         const double rows = GP_TS * ((double)g.ntiles - short_items - 0.5 * diag_items)
                           + (double)g.short_rows * short_items;
         r.flop = 2.0 * GP_TS * GP_TS * rows * (double)(g.k1 - g.k0) * (double)g.nbatch;
         HC(hipEventRecord(r.a, st));
-        launch_tile_gemm(g, st);
+        launch_both();
         HC(hipEventRecord(r.b, st));
     } else {
-        launch_tile_gemm(g, st);
+        launch_both();
     }
     if (dbg_buf) {
         HC(hipStreamSynchronize(st));
@@ -236,7 +266,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
         if (k > ka) {   // column update inside the panel: tile(i,k) -= sum_{kk in [ka,k)} tile(i,kk) tile(k,kk)^T
             GemmArgs g{};
             g.A = M; g.B = M; g.C = M;
-            g.shape = 1; g.i0 = k; g.j0 = k; g.mi = ntot - k; g.mj = 1;
+            g.shape = 1; g.i0 = k; g.j0 = k; g.mi = ntot - k; g.mj = 1; g.sym = 1;
             g.k0 = ka; g.k1 = k; g.accumulate = 1; g.nbatch = nb; g.ntiles = g.mi;
             g.short_row0 = nt; g.short_rows = short_rows;
             gemm(c, g, st);
@@ -254,7 +284,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             GemmArgs g{};
             g.A = M; g.B = M; g.C = M;
             const int m = ntot - kend;
-            g.shape = 0; g.i0 = kend; g.j0 = kend; g.mi = m; g.mj = m;
+            g.shape = 0; g.i0 = kend; g.j0 = kend; g.mi = m; g.mj = m; g.sym = sym_mode();
             g.k0 = ka; g.k1 = kend; g.accumulate = 1; g.nbatch = nb; g.ntiles = m * (m + 1) / 2;
             g.order = tri_order(c, m);
             g.short_row0 = nt; g.short_rows = short_rows;
@@ -454,7 +484,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                     {   // CovITE (+ jitter) = Delta - W W^T, lower tiles
                         GemmArgs g{};
                         g.A = W; g.B = W; g.C = Cm;
-                        g.shape = 0; g.i0 = 0; g.j0 = 0; g.mi = nt; g.mj = nt;
+                        g.shape = 0; g.i0 = 0; g.j0 = 0; g.mi = nt; g.mj = nt; g.sym = sym_mode();
                         g.k0 = 0; g.k1 = nt; g.accumulate = 1; g.nbatch = ub; g.ntiles = (int)nlow;
                         g.order = tri_order(c, nt);
                         gemm(c, g, st);
@@ -608,6 +638,7 @@ int gpslc_destroy(gpslc_ctx* c) {
     (void)hipDeviceSynchronize();
     for (auto s : c->streams) (void)hipStreamDestroy(s);
     for (auto& a : c->arenas) if (a.base) (void)hipFree(a.base);
+    for (int* q : c->queues) if (q) (void)hipFree(q);
     if (c->scratch.base) (void)hipFree(c->scratch.base);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto p : c->tri_order) if (p) (void)hipFree(p);

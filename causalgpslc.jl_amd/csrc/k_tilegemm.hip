@@ -21,6 +21,11 @@
 //     touches four full 128-byte lines;
 //   * C is pre-loaded into the accumulators and the subtraction is done by the MFMA's NEG-A modifier
 //     (the BLGP field of v_mfma_f64), so the epilogue is stores only;
+//   * diagonal tiles of a symmetric update (GemmArgs::sym) need only their lower triangle and go to their own
+//     kernel (tile_syrk_diag_kernel below): of the 8 x 8 grid of 16 x 16 sub-tiles the 36 with column <= row
+//     are dealt 9 per wave (sub-tile rows w and 7 - w) — 9/16 of the MFMAs of a full tile, one operand
+//     stream instead of two.  (Skipping the upper-right quadrant inside this kernel saves nothing: the
+//     workgroup still waits for its three other waves.)
 //   * XCD-aware work split: XCD x (blockIdx % 8) owns the x-th contiguous run of work items, so the
 //     workgroups that share an L2 work on neighbouring tiles of the same matrices.
 #include "gpslc_internal.h"
@@ -79,7 +84,17 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
     }
     const int nslab = (g.k1 - g.k0) * (GP_TS / KS);
 
-    for (long long it = local; it < xc; it += gx) {
+    // Work distribution inside the XCD's run: the first item of a workgroup is `local`; the following ones come
+    // from a per-XCD ticket counter (GemmArgs::queue) when the launch provides one — items differ in cost
+    // (augmented-row tiles, skipped diagonal tiles), a static stride leaves the slowest workgroup ~5 items
+    // behind the mean — or from the static stride otherwise.  The ticket for the NEXT item is requested at the
+    // start of the current one, so its latency hides behind the tile.
+    __shared__ int s_ticket;
+    long long it = local;
+    while (it < xc) {
+        int ticket = 0;
+        if (g.queue && tid == 0) ticket = atomicAdd(&g.queue[xcd], 1);
+        do {
         const long long item = x0 + it;
         const int b = (int)(item / g.ntiles);
         const int t = (int)(item - (long long)b * g.ntiles);
@@ -88,6 +103,8 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         else if (g.shape == 0) tri_decode(t, ii, jj);
         else { ii = t / g.mj; jj = t - ii * g.mj; }
         const int ti = g.i0 + ii, tj = g.j0 + jj;
+        // sym == 2: the full-size diagonal tiles of this launch belong to tile_syrk_diag_kernel
+        if (g.sym == 2 && ti == tj && !(g.short_rows > 0 && ti >= g.short_row0)) break;
 
         double* __restrict__ Ct = tref_tile(g.C, b, ti, tj);
         // augmented right-hand-side rows hold only `short_rows` live rows: this wave's number of live
@@ -228,7 +245,148 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                 d[7] = blockIdx.x;
             }
         }
+        } while (0);
+        if (g.queue) {
+            if (tid == 0) s_ticket = ticket;
+            __syncthreads();
+            it = (long long)gx + s_ticket;
+            __syncthreads();
+        } else {
+            it += gx;
+        }
     }
+    // the last workgroup of the XCD to leave re-arms the counters for the next launch on this stream
+    if (g.queue && tid == 0) {
+        __threadfence();
+        if (atomicAdd(&g.queue[8 + xcd], 1) == gx - 1) {
+            g.queue[xcd] = 0;
+            g.queue[8 + xcd] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Diagonal tiles of a symmetric update:  C(t, t) -= sum_kk A(t, kk) A(t, kk)^T, lower triangle only.
+// Work item = (diagonal tile t in [0, mi), batch element).  Wave w owns sub-tile rows w and 7 - w of the
+// 8 x 8 grid of 16 x 16 sub-tiles: (w, 0..w) and (7 - w, 0..7 - w), 9 sub-tiles, 9 accumulators.  Both MFMA
+// operands come from the one staged A slab.  The strictly-upper sub-tiles of C are never touched (the
+// diagonal-block kernel reads the lower triangle only).
+// ---------------------------------------------------------------------------------------
+#define DG_LDS_BYTES (2 * OPER_LDS * 8)
+
+template <int W>
+__device__ __forceinline__ void syrk_diag_wave(const GemmArgs& g, double* lA, int tid, int lane) {
+    const long long Wk = (long long)g.mi * g.nbatch;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int gx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+    const long long wq = Wk >> 3, wrm = Wk & 7;
+    const long long x0 = xcd * wq + (xcd < wrm ? xcd : wrm);
+    const long long xc = wq + (xcd < wrm ? 1 : 0);
+    int loff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = tid + 256 * u;
+        loff[u] = (q >> 6) * LROW + (q & 63) * 2;
+    }
+    const int nslab = (g.k1 - g.k0) * (GP_TS / KS);
+    const int fbase = (lane >> 4) * LROW + (lane & 15);
+
+    for (long long it = local; it < xc; it += gx) {
+        const long long item = x0 + it;
+        const int b = (int)(item / g.mi);
+        const int t = (int)(item - (long long)b * g.mi);
+        const int ti = g.i0 + t;
+        double* __restrict__ Cd = tref_tile(g.C, b, ti, ti) + ((lane >> 4) * GP_TS + (lane & 15));
+
+        d4 a0c[W + 1], a1c[8 - W];     // sub-tiles (W, cb) and (7 - W, cb)
+#pragma unroll
+        for (int cb = 0; cb <= W; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a0c[cb][v] = Cd[(16 * cb + 4 * v) * GP_TS + 16 * W];
+#pragma unroll
+        for (int cb = 0; cb < 8 - W; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a1c[cb][v] = Cd[(16 * cb + 4 * v) * GP_TS + 16 * (7 - W)];
+
+        d2 ra[4], ra2[4];
+        auto gload = [&](int s, d2 (&xa)[4]) {
+            const int kk = g.k0 + (s >> 3);
+            const double* pa = tref_tile(g.A, b, ti, kk) + (s & 7) * (KS * GP_TS);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xa[u] = *reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2);
+        };
+        auto lstore = [&](int buf, const d2 (&xa)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(lA + buf * OPER_LDS + loff[u]) = xa[u];
+        };
+        auto compute = [&](int buf) {
+            const double* pa = lA + buf * OPER_LDS + fbase;
+#pragma unroll
+            for (int ks = 0; ks < KS / 4; ++ks) {
+                double bf[8 - W];
+#pragma unroll
+                for (int cb = 0; cb < 8 - W; ++cb) bf[cb] = pa[ks * 4 * LROW + 16 * cb];
+                const double r0 = pa[ks * 4 * LROW + 16 * W];
+                const double r1 = pa[ks * 4 * LROW + 16 * (7 - W)];
+#pragma unroll
+                for (int cb = 0; cb <= W; ++cb) a0c[cb] = mfma_step<1>(bf[cb], r0, a0c[cb]);
+#pragma unroll
+                for (int cb = 0; cb < 8 - W; ++cb) a1c[cb] = mfma_step<1>(bf[cb], r1, a1c[cb]);
+            }
+        };
+        if (nslab > 0) {
+            gload(0, ra);
+            lstore(0, ra);
+            gload(1, ra);
+            __syncthreads();
+            for (int s = 0; s < nslab; s += 2) {
+                if (s + 2 < nslab) gload(s + 2, ra2);
+                compute(0);
+                lstore(1, ra);
+                __syncthreads();
+                if (s + 3 < nslab) gload(s + 3, ra);
+                compute(1);
+                if (s + 2 < nslab) lstore(0, ra2);
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb <= W; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Cd[(16 * cb + 4 * v) * GP_TS + 16 * W] = a0c[cb][v];
+#pragma unroll
+        for (int cb = 0; cb < 8 - W; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Cd[(16 * cb + 4 * v) * GP_TS + 16 * (7 - W)] = a1c[cb][v];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void tile_syrk_diag_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // every wave runs the same item loop and the same barriers; only the sub-tile rows differ
+    switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
+        case 0: syrk_diag_wave<0>(g, smem, tid, lane); break;
+        case 1: syrk_diag_wave<1>(g, smem, tid, lane); break;
+        case 2: syrk_diag_wave<2>(g, smem, tid, lane); break;
+        default: syrk_diag_wave<3>(g, smem, tid, lane); break;
+    }
+}
+
+void launch_syrk_diag(const GemmArgs& g, hipStream_t st) {
+    // g.mi = number of full-size diagonal tiles (i0 + t, i0 + t), t < mi; A == B by contract (sym)
+    if (g.mi <= 0 || g.nbatch <= 0 || g.k1 <= g.k0) return;
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = 2 * cus;
+    }
+    const long long Wk = (long long)g.mi * g.nbatch;
+    const unsigned grid = (unsigned)(Wk < slots ? Wk : slots);
+    hipLaunchKernelGGL(tile_syrk_diag_kernel, dim3(grid), dim3(256), DG_LDS_BYTES, st, g);
 }
 
 template <int ACC, int DIAG>
