@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--nu", type=int, default=2)
     ap.add_argument("--levels", type=int, default=1)
-    ap.add_argument("--samples-per-step", type=int, default=512)
+    ap.add_argument("--samples-per-step", type=int, default=1024)
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)
@@ -196,7 +196,7 @@ def main():
             # (separate rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950 correction; tools/profile_r01.sh)
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_tile_gemm.json")
-            if os.path.exists(pmc) and (n, D, K, L, Sr) == (4096, 8, 2, 1, 512) and a.max_batch == 0 and a.panel == 0:
+            if os.path.exists(pmc) and (n, D, K, L, Sr) == (4096, 8, 2, 1, 1024) and a.max_batch == 0 and a.panel == 0:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
