@@ -270,6 +270,10 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
     // a single augmented tile row is the common case and the only one the kernel shortens
     const int short_rows = (aug_rows > 0 && ntot == nt + 1) ? aug_rows : 0;
     const int pw = std::max(1, c->panel);
+    // the tile kernels leave their ticket counters zeroed; re-arm them anyway so that an aborted launch
+    // (device error in an earlier call) can never make a later factorisation skip work items
+    for (size_t i = 0; i < c->streams.size() && i < c->queues.size(); ++i)
+        if (c->streams[i] == st) HC(hipMemsetAsync(c->queues[i], 0, 16 * sizeof(int), st));
     TRef invref = TRef{inv, inv_bstride, 1, 0, 0, 0};   // tile (j, kk) -> inv[kk]
     for (int k = 0; k < nt; ++k) {
         const int ka = (k / pw) * pw;

@@ -114,6 +114,14 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
             const int mt = (g.short_rows + 15) >> 4;
             mlive = min(4, max(0, mt - 4 * wr));
         }
+        // Panel product (ACC == 0): B = inv(L_kk) is lower triangular, so output column block cb needs only the
+        // slabs s <= cb.  With the quadrant layout the two right-hand waves carry 416 of the 1152 live MFMAs
+        // each (critical path 81 % of a full tile for 56 % of its work); here every wave owns ALL 8 row
+        // blocks of the column blocks pw and 7 - pw instead: 32 x ((pw + 1) + (8 - pw)) = 288 MFMAs per wave.
+        // acc[m >> 1][2 (m & 1) + n]: row block m, column block n ? 7 - pw : pw.
+        const int pw = __builtin_amdgcn_readfirstlane(wave);
+        int prow = 8;                                     // live 16-row blocks of this tile
+        if (!ACC && g.short_rows > 0 && ti >= g.short_row0) prow = min(8, (g.short_rows + 15) >> 4);
         unsigned long long st0 = 0, st1 = 0, st2 = 0;
         if (g.dbg) st0 = __builtin_amdgcn_s_memtime();
 
@@ -189,6 +197,28 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                 }
             };
 
+            auto compute_p = [&](int buf, int s) {
+                const int sl = s & 7;
+                if (sl > 7 - pw) return;                   // neither column block needs this slab
+                const bool use0 = sl <= pw;
+                const double* pa = lA + buf * OPER_LDS + (lane >> 4) * LROW + (lane & 15);
+                const double* pb = lB + buf * OPER_LDS + (lane >> 4) * LROW + (lane & 15);
+#pragma unroll
+                for (int ks = 0; ks < KS / 4; ++ks) {
+                    const double b0 = pb[ks * 4 * LROW + 16 * pw];
+                    const double b1 = pb[ks * 4 * LROW + 16 * (7 - pw)];
+                    double af[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) af[m] = pa[ks * 4 * LROW + 16 * m];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+                        if (m < prow) {
+                            if (use0) acc[m >> 1][2 * (m & 1)] = mfma_step<0>(b0, af[m], acc[m >> 1][2 * (m & 1)]);
+                            acc[m >> 1][2 * (m & 1) + 1] = mfma_step<0>(b1, af[m], acc[m >> 1][2 * (m & 1) + 1]);
+                        }
+                }
+            };
+
             gload(0, ra, rb);
             lstore(0, ra, rb);
             gload(1, ra, rb);          // nslab is a multiple of 8
@@ -200,11 +230,11 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
             if (DIAG == 0) {
                 for (int s = 0; s < nslab; s += 2) {
                     if (s + 2 < nslab) gload(s + 2, ra2, rb2);
-                    compute(0, s);
+                    if (ACC) compute(0, s); else compute_p(0, s);
                     lstore(1, ra, rb);
                     __syncthreads();
                     if (s + 3 < nslab) gload(s + 3, ra, rb);
-                    compute(1, s + 1);
+                    if (ACC) compute(1, s + 1); else compute_p(1, s + 1);
                     if (s + 2 < nslab) lstore(0, ra2, rb2);
                     __syncthreads();
                 }
@@ -223,6 +253,18 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
 
         // recompute the store addresses from one opaque offset instead of keeping the 64 preload
         // addresses alive (and spilled) across the K loop
+        if (!ACC) {
+            // panel layout: row block m, column blocks pw (n = 0) and 7 - pw (n = 1); dead rows of a short tile
+            // hold zeros (never accumulated) and are written as such, as before
+            double* __restrict__ Cp = Ct + ((lane >> 4) * GP_TS + (lane & 15));
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    Cp[(16 * pw + 4 * v) * GP_TS + 16 * m] = acc[m >> 1][2 * (m & 1)][v];
+                    Cp[(16 * (7 - pw) + 4 * v) * GP_TS + 16 * m] = acc[m >> 1][2 * (m & 1) + 1][v];
+                }
+        } else {
         int soff = ccol * GP_TS + crow;
         asm volatile("" : "+v"(soff));
         double* __restrict__ Cs = Ct + soff;
@@ -233,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
                     Cs[(16 * n + 4 * v) * GP_TS + 16 * m] = acc[m][n][v];
+        }
         if (g.dbg) {   // diagnostic stamps: go to a buffer nothing else reads
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long st3 = __builtin_amdgcn_s_memtime();
