@@ -29,6 +29,7 @@
 //   * XCD-aware work split: XCD x (blockIdx % 8) owns the x-th contiguous run of work items, so the
 //     workgroups that share an L2 work on neighbouring tiles of the same matrices.
 #include "gpslc_internal.h"
+#include <cstdlib>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -426,6 +427,7 @@ void launch_syrk_diag(const GemmArgs& g, hipStream_t st) {
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         slots = 2 * cus;
+        if (const char* e = getenv("GPSLC_GEMM_SLOTS")) slots = atoi(e);
     }
     const long long Wk = (long long)g.mi * g.nbatch;
     const unsigned grid = (unsigned)(Wk < slots ? Wk : slots);
@@ -451,6 +453,7 @@ void launch_tile_gemm(const GemmArgs& g, hipStream_t st) {
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         slots = 2 * cus;   // 2 workgroups per CU (227 VGPRs, 72 KiB LDS each)
+        if (const char* e = getenv("GPSLC_GEMM_SLOTS")) slots = atoi(e);   // experiments only
     }
     const long long W = (long long)g.ntiles * g.nbatch;
     const unsigned grid = (unsigned)(W < slots ? W : slots);
