@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Unit B + C of SURVEY.md §8d on one GPU: full ITE covariance + its factor + predictive draws per (sample, level)
+(what sampleITE / predictCounterfactualEffects cost), host-pointer API.  Usage: bench_unit_b.py [N S L spp]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import causalgpslc_jl_amd as gp          # noqa: E402
+from causalgpslc_jl_amd import synth    # noqa: E402
+
+n, S, L, spp = (int(a) for a in (sys.argv[1:5] + ["4096", "128", "1", "8"][len(sys.argv) - 1:]))
+D, K = 8, 2
+X, T, Y, obj = synth.make_dataset(n, D)
+post = synth.make_posterior(n, D, K, S, obj, seed=1234)
+g = gp.GPSLCObject(X, T, Y, post["U"], post["uyLS"], post["xyLS"], post["tyLS"], post["yNoise"], post["yScale"])
+doTs = synth.levels(T, L)
+gp.predict(g, doTs[:1], spp=2, seed=1, want_draws=True)     # warm-up (arenas, first-touch)
+t0 = time.perf_counter()
+ms, vs, mi, dr = gp.predict(g, doTs, spp=spp, seed=7, want_draws=True)
+dt = time.perf_counter() - t0
+assert np.all(np.isfinite(dr))
+units = S * L
+print(f"N={n} S={S} L={L} spp={spp}: {units / dt:.1f} (sample, level) units/s, {units * spp / dt:.0f} draws/s, "
+      f"{dt * 1e3:.0f} ms; unit-B ceiling at 78.6 TFLOP/s = {78.6e12 / (7.0 / 3.0 * n ** 3):.0f}/s")
