@@ -142,6 +142,14 @@ static int col_sym_mode() {
     return m;
 }
 
+// with a single short augmented tile row, its off-diagonal tiles ride with the diagonal items (GemmArgs::sym == 3)
+static int aug_sym(int sym, int short_rows) {
+    static const int on = [] { const char* e = getenv("GPSLC_SYRK_AUG"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    // up to 32 live rows (31 levels): beyond that the diagonal kernel runs out of registers and the augmented
+    // tiles carry enough real work to stay ordinary items
+    return (sym == 2 && short_rows > 0 && short_rows <= 32 && on) ? 3 : sym;
+}
+
 void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
     static const int diag_skip = getenv("GPSLC_GEMM_DIAG") ? atoi(getenv("GPSLC_GEMM_DIAG")) : 0;
@@ -165,11 +173,11 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
     if (g.ntiles <= 0 || g.nbatch <= 0 || (g.k1 <= g.k0 && g.accumulate)) return;
     // sym == 2: the full-size diagonal tiles (those above the augmented rows) go to the lower-triangle kernel
     auto launch_diag_tiles = [&]() {
-        if (g.sym == 2 && g.i0 == g.j0 && g.diag_skip == 0) {
+        if (g.sym >= 2 && g.i0 == g.j0 && (g.diag_skip == 0 || g.diag_skip == 3)) {
             GemmArgs d = g;
             const int cand = g.shape == 0 ? g.mi : 1;      // a column update holds one diagonal tile
             d.mi = g.short_rows > 0 ? std::max(0, std::min(cand, g.short_row0 - g.i0)) : cand;
-            launch_syrk_diag(d, st);
+            launch_syrk_diag(d, g.sym == 3 && g.short_rows > 0 && g.diag_skip == 0, st);
         }
     };
     const bool prof = (c->flags & GPSLC_FLAG_PROFILE) && g.accumulate;
@@ -197,9 +205,12 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
         if (short_items > 0 && g.shape == 0) diag_items -= 1.0;
         // sym == 2: this kernel does not run the full-size diagonal tiles at all (launch_syrk_diag does, outside the
         // timed bracket, so that the HIP-event average equals rocprofv3's average for the dominant kernel)
-        const double diag_out = (g.sym == 2 && g.i0 == g.j0 && g.diag_skip == 0) ? 1.0 : 0.5;
+        const double diag_out = (g.sym >= 2 && g.i0 == g.j0 && (g.diag_skip == 0 || g.diag_skip == 3)) ? 1.0 : 0.5;
+        // sym == 3: the off-diagonal augmented-row tiles are not this kernel's either (they ride with the diagonal items)
+        double short_exec = short_items;
+        if (g.sym == 3 && short_items > 0) short_exec = (g.shape == 0) ? 1.0 : 0.0;
         const double rows = GP_TS * ((double)g.ntiles - short_items - diag_out * diag_items)
-                          + (double)g.short_rows * short_items;
+                          + (double)g.short_rows * short_exec;
         r.flop = 2.0 * GP_TS * GP_TS * rows * (double)(g.k1 - g.k0) * (double)g.nbatch;
         HC(hipEventRecord(r.a, st));
         launch_tile_gemm(g, st);
@@ -281,7 +292,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
         if (k > ka) {   // column update inside the panel: tile(i,k) -= sum_{kk in [ka,k)} tile(i,kk) tile(k,kk)^T
             GemmArgs g{};
             g.A = M; g.B = M; g.C = M;
-            g.shape = 1; g.i0 = k; g.j0 = k; g.mi = ntot - k; g.mj = 1; g.sym = col_sym_mode();
+            g.shape = 1; g.i0 = k; g.j0 = k; g.mi = ntot - k; g.mj = 1; g.sym = aug_sym(col_sym_mode(), short_rows);
             g.k0 = ka; g.k1 = k; g.accumulate = 1; g.nbatch = nb; g.ntiles = g.mi;
             g.short_row0 = nt; g.short_rows = short_rows;
             gemm(c, g, st);
@@ -299,7 +310,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             GemmArgs g{};
             g.A = M; g.B = M; g.C = M;
             const int m = ntot - kend;
-            g.shape = 0; g.i0 = kend; g.j0 = kend; g.mi = m; g.mj = m; g.sym = sym_mode();
+            g.shape = 0; g.i0 = kend; g.j0 = kend; g.mi = m; g.mj = m; g.sym = aug_sym(sym_mode(), short_rows);
             g.k0 = ka; g.k1 = kend; g.accumulate = 1; g.nbatch = nb; g.ntiles = m * (m + 1) / 2;
             g.order = tri_order(c, m);
             g.short_row0 = nt; g.short_rows = short_rows;

@@ -44,7 +44,8 @@ struct GemmArgs {
     int short_rows;   // `short_rows` live rows: dead 16-row sub-tiles are skipped (0 = feature off)
     int sym;          // A and B are the same tile matrix and C(t, t) needs only its lower triangle.  1: noted for
                       // the flop accounting only; 2: launch_tile_gemm skips the full-size diagonal tiles, which
-                      // launch_syrk_diag (36 of 64 sub-tile products, 9 per wave) computes instead
+                      // launch_syrk_diag (36 of 64 sub-tile products, 9 per wave) computes instead; 3: as 2, and
+                      // the augmented-row tiles (short_row0, j) of those columns ride with the diagonal items too
     int* queue;       // optional: 16 zero-initialised ints (per-XCD ticket counters [0..8), exit counters [8..16))
                       // owned by the launching stream; the kernel leaves them zeroed again.  null = static stride
     const unsigned short* order;  // optional (ii, jj) pairs: output-tile visiting order (L2-blocked), or null
@@ -78,7 +79,7 @@ struct GramArgs {
 
 // launchers (implemented in the k_*.hip files); all asynchronous on `st`
 void launch_tile_gemm(const GemmArgs& g, hipStream_t st);
-void launch_syrk_diag(const GemmArgs& g, hipStream_t st);   // g.mi full-size diagonal tiles from (i0, i0)
+void launch_syrk_diag(const GemmArgs& g, int carry_aug, hipStream_t st);   // g.mi full-size diagonal tiles from (i0, i0)
 void launch_diag(const TRef& M, int k, double* inv, long long inv_bstride, int* info,
                  int info_base, int nbatch, hipStream_t st);
 void launch_gram(const GramArgs& g, int nbatch, hipStream_t st);

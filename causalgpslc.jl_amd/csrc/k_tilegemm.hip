@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         else { ii = t / g.mj; jj = t - ii * g.mj; }
         const int ti = g.i0 + ii, tj = g.j0 + jj;
         // sym == 2: the full-size diagonal tiles of this launch belong to tile_syrk_diag_kernel
-        if (g.sym == 2 && ti == tj && !(g.short_rows > 0 && ti >= g.short_row0)) break;
+        if (g.sym >= 2 && ti == tj && !(g.short_rows > 0 && ti >= g.short_row0)) break;
+        // sym == 3: the augmented-row tiles of the columns that have a full-size diagonal tile ride with it
+        if (g.sym == 3 && g.short_rows > 0 && ti >= g.short_row0 && tj < g.short_row0) break;
+        if (g.diag_skip == 3 && g.short_rows > 0 && ti >= g.short_row0) break;   // timing-only: price of the short tiles
 
         double* __restrict__ Ct = tref_tile(g.C, b, ti, tj);
         // augmented right-hand-side rows hold only `short_rows` live rows: this wave's number of live
@@ -315,11 +318,18 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
 // 8 x 8 grid of 16 x 16 sub-tiles: (w, 0..w) and (7 - w, 0..7 - w), 9 sub-tiles, 9 accumulators.  Both MFMA
 // operands come from the one staged A slab.  The strictly-upper sub-tiles of C are never touched (the
 // diagonal-block kernel reads the lower triangle only).
+//
+// MT > 0: the item also carries the augmented (right-hand-side) row of its column,
+//     C(aug, t) -= sum_kk A(aug, kk) A(t, kk)^T      for the first 16 MT rows of the tile,
+// because it streams exactly the operand that update needs (A(t, kk)): as work items of the general kernel the
+// augmented-row tiles cost 3.9 % of its time (measured, GPSLC_GEMM_DIAG=3) for 0.1 % of the flops — each one
+// streams two full operand panels for two live rows.  Wave w takes column blocks w and 7 - w of those rows.
 // ---------------------------------------------------------------------------------------
-#define DG_LDS_BYTES (2 * OPER_LDS * 8)
+#define DG_LDS_BYTES(MT) ((2 * OPER_LDS + ((MT) > 0 ? 2 * OPER_LDS : 0)) * 8)
 
-template <int W>
+template <int W, int MT>
 __device__ __forceinline__ void syrk_diag_wave(const GemmArgs& g, double* lA, int tid, int lane) {
+    double* lG = lA + 2 * OPER_LDS;      // augmented-row slabs (MT > 0)
     const long long Wk = (long long)g.mi * g.nbatch;
     const int G = gridDim.x;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
@@ -333,6 +343,8 @@ __device__ __forceinline__ void syrk_diag_wave(const GemmArgs& g, double* lA, in
         const int q = tid + 256 * u;
         loff[u] = (q >> 6) * LROW + (q & 63) * 2;
     }
+    // rows [0, 16 MT) of an augmented slab: the chunks of this thread whose row pair is live
+    const bool glive = MT > 0 && ((tid & 63) * 2) < 16 * MT;
     const int nslab = (g.k1 - g.k0) * (GP_TS / KS);
     const int fbase = (lane >> 4) * LROW + (lane & 15);
 
@@ -342,6 +354,7 @@ __device__ __forceinline__ void syrk_diag_wave(const GemmArgs& g, double* lA, in
         const int t = (int)(item - (long long)b * g.mi);
         const int ti = g.i0 + t;
         double* __restrict__ Cd = tref_tile(g.C, b, ti, ti) + ((lane >> 4) * GP_TS + (lane & 15));
+        double* __restrict__ Cg = MT > 0 ? tref_tile(g.C, b, g.short_row0, ti) + ((lane >> 4) * GP_TS + (lane & 15)) : nullptr;
 
         d4 a0c[W + 1], a1c[8 - W];     // sub-tiles (W, cb) and (7 - W, cb)
 #pragma unroll
@@ -352,20 +365,46 @@ __device__ __forceinline__ void syrk_diag_wave(const GemmArgs& g, double* lA, in
         for (int cb = 0; cb < 8 - W; ++cb)
 #pragma unroll
             for (int v = 0; v < 4; ++v) a1c[cb][v] = Cd[(16 * cb + 4 * v) * GP_TS + 16 * (7 - W)];
+        d4 ag[MT > 0 ? MT : 1][2];     // augmented rows: row block m, column blocks W (0) and 7 - W (1)
+        if (MT > 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    ag[m][0][v] = Cg[(16 * W + 4 * v) * GP_TS + 16 * m];
+                    ag[m][1][v] = Cg[(16 * (7 - W) + 4 * v) * GP_TS + 16 * m];
+                }
+        }
 
         d2 ra[4], ra2[4];
+        d2 rg[4];       // augmented slab: one staging set, loaded one slab ahead (a few live rows, L2-resident)
         auto gload = [&](int s, d2 (&xa)[4]) {
             const int kk = g.k0 + (s >> 3);
             const double* pa = tref_tile(g.A, b, ti, kk) + (s & 7) * (KS * GP_TS);
 #pragma unroll
             for (int u = 0; u < 4; ++u) xa[u] = *reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2);
         };
+        auto gload_g = [&](int s) {
+            if (MT > 0 && glive) {
+                const int kk = g.k0 + (s >> 3);
+                const double* pg = tref_tile(g.A, b, g.short_row0, kk) + (s & 7) * (KS * GP_TS);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rg[u] = *reinterpret_cast<const d2*>(pg + (tid + 256 * u) * 2);
+            }
+        };
         auto lstore = [&](int buf, const d2 (&xa)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(lA + buf * OPER_LDS + loff[u]) = xa[u];
         };
+        auto lstore_g = [&](int buf) {
+            if (MT > 0 && glive) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(lG + buf * OPER_LDS + loff[u]) = rg[u];
+            }
+        };
         auto compute = [&](int buf) {
             const double* pa = lA + buf * OPER_LDS + fbase;
+            const double* pg = lG + buf * OPER_LDS + fbase;
 #pragma unroll
             for (int ks = 0; ks < KS / 4; ++ks) {
                 double bf[8 - W];
@@ -377,21 +416,34 @@ __device__ __forceinline__ void syrk_diag_wave(const GemmArgs& g, double* lA, in
                 for (int cb = 0; cb <= W; ++cb) a0c[cb] = mfma_step<1>(bf[cb], r0, a0c[cb]);
 #pragma unroll
                 for (int cb = 0; cb < 8 - W; ++cb) a1c[cb] = mfma_step<1>(bf[cb], r1, a1c[cb]);
+                if (MT > 0) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const double gf = pg[ks * 4 * LROW + 16 * m];
+                        ag[m][0] = mfma_step<1>(bf[W], gf, ag[m][0]);
+                        ag[m][1] = mfma_step<1>(bf[7 - W], gf, ag[m][1]);
+                    }
+                }
             }
         };
         if (nslab > 0) {
             gload(0, ra);
+            gload_g(0);
             lstore(0, ra);
+            lstore_g(0);
             gload(1, ra);
             __syncthreads();
             for (int s = 0; s < nslab; s += 2) {
                 if (s + 2 < nslab) gload(s + 2, ra2);
+                gload_g(s + 1);
                 compute(0);
                 lstore(1, ra);
+                lstore_g(1);
                 __syncthreads();
                 if (s + 3 < nslab) gload(s + 3, ra);
+                if (s + 2 < nslab) gload_g(s + 2);
                 compute(1);
-                if (s + 2 < nslab) lstore(0, ra2);
+                if (s + 2 < nslab) { lstore(0, ra2); lstore_g(0); }
                 __syncthreads();
             }
         }
@@ -403,23 +455,45 @@ __device__ __forceinline__ void syrk_diag_wave(const GemmArgs& g, double* lA, in
         for (int cb = 0; cb < 8 - W; ++cb)
 #pragma unroll
             for (int v = 0; v < 4; ++v) Cd[(16 * cb + 4 * v) * GP_TS + 16 * (7 - W)] = a1c[cb][v];
+        if (MT > 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    Cg[(16 * W + 4 * v) * GP_TS + 16 * m] = ag[m][0][v];
+                    Cg[(16 * (7 - W) + 4 * v) * GP_TS + 16 * m] = ag[m][1][v];
+                }
+        }
     }
 }
 
+template <int MT>
 __global__ __launch_bounds__(256, 2) void tile_syrk_diag_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // every wave runs the same item loop and the same barriers; only the sub-tile rows differ
     switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
-        case 0: syrk_diag_wave<0>(g, smem, tid, lane); break;
-        case 1: syrk_diag_wave<1>(g, smem, tid, lane); break;
-        case 2: syrk_diag_wave<2>(g, smem, tid, lane); break;
-        default: syrk_diag_wave<3>(g, smem, tid, lane); break;
+        case 0: syrk_diag_wave<0, MT>(g, smem, tid, lane); break;
+        case 1: syrk_diag_wave<1, MT>(g, smem, tid, lane); break;
+        case 2: syrk_diag_wave<2, MT>(g, smem, tid, lane); break;
+        default: syrk_diag_wave<3, MT>(g, smem, tid, lane); break;
     }
 }
 
-void launch_syrk_diag(const GemmArgs& g, hipStream_t st) {
-    // g.mi = number of full-size diagonal tiles (i0 + t, i0 + t), t < mi; A == B by contract (sym)
+template <int MT>
+static void launch_syrk_diag_t(const GemmArgs& g, unsigned grid, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)tile_syrk_diag_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  DG_LDS_BYTES(MT));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(tile_syrk_diag_kernel<MT>, dim3(grid), dim3(256), DG_LDS_BYTES(MT), st, g);
+}
+
+// g.mi = number of full-size diagonal tiles (i0 + t, i0 + t), t < mi; A == B by contract (sym).
+// carry_aug: the items also update the augmented-row tiles (short_row0, i0 + t) (live rows g.short_rows).
+void launch_syrk_diag(const GemmArgs& g, int carry_aug, hipStream_t st) {
     if (g.mi <= 0 || g.nbatch <= 0 || g.k1 <= g.k0) return;
     static int slots = 0;
     if (slots == 0) {
@@ -427,11 +501,13 @@ void launch_syrk_diag(const GemmArgs& g, hipStream_t st) {
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         slots = 2 * cus;
-        if (const char* e = getenv("GPSLC_GEMM_SLOTS")) slots = atoi(e);
     }
     const long long Wk = (long long)g.mi * g.nbatch;
     const unsigned grid = (unsigned)(Wk < slots ? Wk : slots);
-    hipLaunchKernelGGL(tile_syrk_diag_kernel, dim3(grid), dim3(256), DG_LDS_BYTES, st, g);
+    const int mt = carry_aug ? (g.short_rows + 15) / 16 : 0;   // callers pass carry_aug only for mt <= 2
+    if (mt == 0) launch_syrk_diag_t<0>(g, grid, st);
+    else if (mt == 1) launch_syrk_diag_t<1>(g, grid, st);
+    else launch_syrk_diag_t<2>(g, grid, st);
 }
 
 template <int ACC, int DIAG>
