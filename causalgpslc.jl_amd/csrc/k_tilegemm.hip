@@ -156,9 +156,12 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                 const int so = (s & 7) * (KS * GP_TS);
                 const double* pa = tref_tile(g.A, b, ti, kk) + so;
                 const double* pb = tref_tile(g.B, b, tj, kk) + so;
+                // panel product of a short (augmented-row) tile: the chunks of A below its live rows are never
+                // used — point them at chunk 0 of their k-column's line instead of streaming zeros
+                const int ao = (!ACC && ((tid & 63) * 2) >= 16 * prow) ? (tid & ~63) * 2 : tid * 2;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    xa[u] = *reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2);
+                    xa[u] = *reinterpret_cast<const d2*>(pa + ao + 512 * u);
                     xb[u] = *reinterpret_cast<const d2*>(pb + (tid + 256 * u) * 2);
                 }
             };
@@ -259,14 +262,16 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         // addresses alive (and spilled) across the K loop
         if (!ACC) {
             // panel layout: row block m, column blocks pw (n = 0) and 7 - pw (n = 1); dead rows of a short tile
-            // hold zeros (never accumulated) and are written as such, as before
+            // hold zeros (never accumulated, never written)
             double* __restrict__ Cp = Ct + ((lane >> 4) * GP_TS + (lane & 15));
 #pragma unroll
             for (int m = 0; m < 8; ++m)
+                if (m < prow) {     // the dead row blocks of a short tile keep their zeros
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    Cp[(16 * pw + 4 * v) * GP_TS + 16 * m] = acc[m >> 1][2 * (m & 1)][v];
-                    Cp[(16 * (7 - pw) + 4 * v) * GP_TS + 16 * m] = acc[m >> 1][2 * (m & 1) + 1][v];
+                    for (int v = 0; v < 4; ++v) {
+                        Cp[(16 * pw + 4 * v) * GP_TS + 16 * m] = acc[m >> 1][2 * (m & 1)][v];
+                        Cp[(16 * (7 - pw) + 4 * v) * GP_TS + 16 * m] = acc[m >> 1][2 * (m & 1) + 1][v];
+                    }
                 }
         } else {
         int soff = ccol * GP_TS + crow;
