@@ -91,3 +91,21 @@ def test_mvn_not_positive_definite(gp):
     cov = np.ones((6, 6))
     with pytest.raises(gp.PosDefException):
         gp.mvnLogpdf(cov, np.ones(6))
+
+
+@pytest.mark.parametrize("j", [0, 1, 15, 16, 17, 100, 127, 128, 129, 200, 271, 299])
+def test_failing_pivot_is_reported_like_lapack(gp, j):
+    """The first non-positive pivot comes back as LAPACK's info (1-based), across 16 x 16 sub-block and
+    128 x 128 tile boundaries of the diagonal-block kernel — what PDMats turns into PosDefException(info)."""
+    n = 300
+    rng = np.random.default_rng(j)
+    d = 1.0 + rng.random(n)
+    d[j] = -0.5
+    cov = np.diag(d)
+    # couple the leading block so that the factorisation does real work before the bad pivot
+    if j > 2:
+        v = 0.1 * rng.standard_normal(j)
+        cov[:j, :j] += np.outer(v, v)
+    with pytest.raises(gp.PosDefException) as ei:
+        gp.mvnLogpdf(cov, rng.standard_normal(n))
+    assert ei.value.info == j + 1
