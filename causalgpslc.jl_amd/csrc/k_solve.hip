@@ -387,6 +387,9 @@ static void launch_ite_mean_mfma_t(const IteMeanArgs& a, int nbatch, hipStream_t
 static void launch_ite_mean_mfma(const IteMeanArgs& a, int nbatch, hipStream_t st) {
     const int F = a.nU + a.nX;
     if (F <= 4) launch_ite_mean_mfma_t<4>(a, nbatch, st);
+    else if (F <= 6) launch_ite_mean_mfma_t<6>(a, nbatch, st);
+    else if (F <= 8) launch_ite_mean_mfma_t<8>(a, nbatch, st);
+    else if (F <= 10) launch_ite_mean_mfma_t<10>(a, nbatch, st);
     else if (F <= 12) launch_ite_mean_mfma_t<12>(a, nbatch, st);
     else launch_ite_mean_mfma_t<0>(a, nbatch, st);
 }
