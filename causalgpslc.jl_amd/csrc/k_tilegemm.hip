@@ -537,7 +537,9 @@ void launch_tile_gemm(const GemmArgs& g, hipStream_t st) {
         if (const char* e = getenv("GPSLC_GEMM_SLOTS")) slots = atoi(e);   // experiments only
     }
     const long long W = (long long)g.ntiles * g.nbatch;
-    const unsigned grid = (unsigned)(W < slots ? W : slots);
+    static const int panel_slots = [] { const char* e = getenv("GPSLC_PANEL_SLOTS"); return e ? atoi(e) : 0; }();
+    const int use_slots = (!g.accumulate && panel_slots > 0) ? panel_slots : slots;   // experiments only
+    const unsigned grid = (unsigned)(W < use_slots ? W : use_slots);
     if (g.diag_skip == 1) {        // timing-only diagnostics (GPSLC_GEMM_DIAG), separate instantiations
         if (g.accumulate) launch_one<1, 1>(g, grid, st); else launch_one<0, 1>(g, grid, st);
     } else if (g.diag_skip == 2) {
