@@ -150,6 +150,20 @@ static int aug_sym(int sym, int short_rows) {
     return (sym == 2 && short_rows > 0 && short_rows <= 32 && on) ? 3 : sym;
 }
 
+// GPSLC_FUSE_PANEL=0: separate panel-product launches for every column (measurement switch)
+static int fuse_mode() {
+    static const int m = [] { const char* e = getenv("GPSLC_FUSE_PANEL"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    return m;
+}
+
+// the diagonal tile (and, with sym == 3, the augmented-row tile) of a symmetric column update, on its own
+static void launch_sym_diag_tiles(const GemmArgs& g, hipStream_t st) {
+    GemmArgs d = g;
+    const int cand = g.shape == 0 ? g.mi : 1;
+    d.mi = g.short_rows > 0 ? std::max(0, std::min(cand, g.short_row0 - g.i0)) : cand;
+    launch_syrk_diag(d, g.sym == 3 && g.short_rows > 0, st);
+}
+
 void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
     static const int diag_skip = getenv("GPSLC_GEMM_DIAG") ? atoi(getenv("GPSLC_GEMM_DIAG")) : 0;
@@ -173,6 +187,7 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
     if (g.ntiles <= 0 || g.nbatch <= 0 || (g.k1 <= g.k0 && g.accumulate)) return;
     // sym == 2: the full-size diagonal tiles (those above the augmented rows) go to the lower-triangle kernel
     auto launch_diag_tiles = [&]() {
+        if (g.fuse) return;     // potrf_tiles launched them before the diagonal-block kernel (launch_sym_diag_tiles)
         if (g.sym >= 2 && g.i0 == g.j0 && (g.diag_skip == 0 || g.diag_skip == 3)) {
             GemmArgs d = g;
             const int cand = g.shape == 0 ? g.mi : 1;      // a column update holds one diagonal tile
@@ -212,6 +227,9 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
         const double rows = GP_TS * ((double)g.ntiles - short_items - diag_out * diag_items)
                           + (double)g.short_rows * short_exec;
         r.flop = 2.0 * GP_TS * GP_TS * rows * (double)(g.k1 - g.k0) * (double)g.nbatch;
+        // fused panel product: one triangular solve per tile row = 128^2 * 128 multiply-adds... counted as the
+        // textbook n^2 b flop of a TRSM (the kernel runs 56 % of the dense 2*128^3 product)
+        if (g.fuse) r.flop += (double)GP_TS * GP_TS * rows * (double)g.nbatch;
         HC(hipEventRecord(r.a, st));
         launch_tile_gemm(g, st);
         HC(hipEventRecord(r.b, st));
@@ -289,16 +307,27 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
     for (int k = 0; k < nt; ++k) {
         const int ka = (k / pw) * pw;
         const int kend = std::min(ka + pw, nt);
+        bool fused = false;
         if (k > ka) {   // column update inside the panel: tile(i,k) -= sum_{kk in [ka,k)} tile(i,kk) tile(k,kk)^T
             GemmArgs g{};
             g.A = M; g.B = M; g.C = M;
             g.shape = 1; g.i0 = k; g.j0 = k; g.mi = ntot - k; g.mj = 1; g.sym = aug_sym(col_sym_mode(), short_rows);
             g.k0 = ka; g.k1 = k; g.accumulate = 1; g.nbatch = nb; g.ntiles = g.mi;
             g.short_row0 = nt; g.short_rows = short_rows;
-            gemm(c, g, st);
+            if (g.sym >= 2 && fuse_mode() && ntot - k - 1 > 0) {
+                // diagonal tile first, then its factor + inverse, then ONE pass over the column: update and panel
+                // product of every tile below the diagonal (the column makes one HBM round trip instead of two)
+                launch_sym_diag_tiles(g, st);
+                launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
+                g.fuse = 1; g.F = invref; g.fk = k;
+                gemm(c, g, st);
+                fused = true;
+            } else {
+                gemm(c, g, st);
+            }
         }
-        launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
-        if (ntot - k - 1 > 0) {   // panel: tile(i,k) = tile(i,k) * inv(L_kk)^T
+        if (!fused) launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
+        if (!fused && ntot - k - 1 > 0) {   // panel: tile(i,k) = tile(i,k) * inv(L_kk)^T
             GemmArgs g{};
             g.A = M; g.B = invref; g.C = M;
             g.shape = 1; g.i0 = k + 1; g.j0 = k; g.mi = ntot - k - 1; g.mj = 1;

@@ -46,6 +46,9 @@ struct GemmArgs {
                       // the flop accounting only; 2: launch_tile_gemm skips the full-size diagonal tiles, which
                       // launch_syrk_diag (36 of 64 sub-tile products, 9 per wave) computes instead; 3: as 2, and
                       // the augmented-row tiles (short_row0, j) of those columns ride with the diagonal items too
+    int fuse;         // 1 (accumulate launches of one tile column, mj == 1): each item also applies the panel
+    TRef F;           //    product with tile (0, fk) of F = the inverted diagonal blocks (see k_tilegemm.hip)
+    int fk;
     int* queue;       // optional: 16 zero-initialised ints (per-XCD ticket counters [0..8), exit counters [8..16))
                       // owned by the launching stream; the kernel leaves them zeroed again.  null = static stride
     const unsigned short* order;  // optional (ii, jj) pairs: output-tile visiting order (L2-blocked), or null

@@ -54,7 +54,16 @@ __device__ __forceinline__ d4 mfma_step(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, NEG);
 }
 
-template <int ACC, int DIAG>
+// FUSE = 1 (ACC = 1 only): the in-panel column update AND the panel product of the same tile in one item,
+//     X = C(i,k) - sum_kk A(i,kk) B(k,kk)^T   (the K loop, X stays in the accumulators)
+//     L(i,k) = X * inv(L_kk)^T                  (second phase, GemmArgs::F holds the inverted diagonal blocks)
+// so the column tiles make one HBM round trip instead of two (the separate panel product is HBM bound: 127 MB per
+// sample).  The accumulator layout (row = lane&15, col = (lane>>4) + 4v) IS the k-layout of an MFMA operand, so
+// X feeds the second product straight from the registers; only the 64 x 64 block X(:, 0:64) * W(64:128, 0:64)^T
+// crosses from the left-hand waves to the right-hand ones, through the (idle) staging LDS.  inv(L_kk) is lower
+// triangular: sub-block products above its diagonal are skipped.  Summation order per output element = ascending
+// column of X, as in the separate panel kernel.
+template <int ACC, int DIAG, int FUSE = 0>
 __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
@@ -107,7 +116,12 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         // sym == 2: the full-size diagonal tiles of this launch belong to tile_syrk_diag_kernel
         if (g.sym >= 2 && ti == tj && !(g.short_rows > 0 && ti >= g.short_row0)) break;
         // sym == 3: the augmented-row tiles of the columns that have a full-size diagonal tile ride with it
-        if (g.sym == 3 && g.short_rows > 0 && ti >= g.short_row0 && tj < g.short_row0) break;
+        bool no_update = false;     // FUSE: the augmented tile was already updated (it rode with the diagonal item);
+                                    // it only takes the panel product here
+        if (g.sym == 3 && g.short_rows > 0 && ti >= g.short_row0 && tj < g.short_row0) {
+            if (!FUSE) break;
+            no_update = true;
+        }
         if (g.diag_skip == 3 && g.short_rows > 0 && ti >= g.short_row0) break;   // timing-only: price of the short tiles
 
         double* __restrict__ Ct = tref_tile(g.C, b, ti, tj);
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                 for (int n = 0; n < 4; ++n) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
         }
 
-        if (nslab > 0) {
+        if (nslab > 0 && !no_update) {
             // staging: 16 KiB per operand per slab = 1024 16-byte chunks, 4 per thread, contiguous in HBM
             d2 ra[4], rb[4];     // staging set A
             d2 ra2[4], rb2[4];   // staging set B: loads run two slabs ahead of the MFMAs
@@ -258,6 +272,63 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         }
         if (g.dbg) st2 = __builtin_amdgcn_s_memtime();
 
+        if (FUSE) {
+            const int li = lane & 15, lg = lane >> 4;
+            const double* __restrict__ Wl = tref_tile(g.F, b, 0, g.fk) + (lg * GP_TS + li);   // W(c, c') at c'*128 + c
+            double* lP = smem;                                   // [wr][nc][m][v][64 lanes], 64 KiB
+            if (nslab == 0 || no_update) __syncthreads();        // (the K loop ends with a barrier otherwise)
+            if (wc == 0) {
+                // X(:, 0:64) * W(64:128, 0:64)^T for the right-hand waves
+#pragma unroll
+                for (int nc = 0; nc < 4; ++nc) {
+                    d4 st[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) st[m] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const double w = Wl[(16 * n + 4 * v) * GP_TS + 64 + 16 * nc];
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) st[m] = mfma_step<0>(w, acc[m][n][v], st[m]);
+                        }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) lP[((((wr * 4 + nc) * 4 + m) * 4 + v) << 6) + lane] = st[m][v];
+                }
+            }
+            __syncthreads();
+            double* __restrict__ Co = Ct + ((wc * 64 + lg) * GP_TS + wr * 64 + li);
+            const double* __restrict__ Wq = Wl + (64 * wc) * GP_TS + 64 * wc;     // the wave's diagonal quadrant of W
+#pragma unroll
+            for (int nc = 0; nc < 4; ++nc) {
+                d4 st[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (wc == 0) st[m] = (d4){0.0, 0.0, 0.0, 0.0};
+                    else {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) st[m][v] = lP[((((wr * 4 + nc) * 4 + m) * 4 + v) << 6) + lane];
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (n <= nc) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const double w = Wq[(16 * n + 4 * v) * GP_TS + 16 * nc];
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) st[m] = mfma_step<0>(w, acc[m][n][v], st[m]);
+                        }
+                    }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) Co[(16 * nc + 4 * v) * GP_TS + 16 * m] = st[m][v];
+            }
+            __syncthreads();     // lP is the staging area of the next item
+        } else {
         // recompute the store addresses from one opaque offset instead of keeping the 64 preload
         // addresses alive (and spilled) across the K loop
         if (!ACC) {
@@ -284,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
                     Cs[(16 * n + 4 * v) * GP_TS + 16 * m] = acc[m][n][v];
+        }
         }
         if (g.dbg) {   // diagnostic stamps: go to a buffer nothing else reads
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -515,15 +587,15 @@ void launch_syrk_diag(const GemmArgs& g, int carry_aug, hipStream_t st) {
     else launch_syrk_diag_t<2>(g, grid, st);
 }
 
-template <int ACC, int DIAG>
+template <int ACC, int DIAG, int FUSE = 0>
 static void launch_one(const GemmArgs& g, unsigned grid, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tile_gemm_nt_kernel<ACC, DIAG>,
+        (void)hipFuncSetAttribute((const void*)tile_gemm_nt_kernel<ACC, DIAG, FUSE>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((tile_gemm_nt_kernel<ACC, DIAG>), dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
+    hipLaunchKernelGGL((tile_gemm_nt_kernel<ACC, DIAG, FUSE>), dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
 }
 
 void launch_tile_gemm(const GemmArgs& g, hipStream_t st) {
@@ -544,6 +616,8 @@ void launch_tile_gemm(const GemmArgs& g, hipStream_t st) {
         if (g.accumulate) launch_one<1, 1>(g, grid, st); else launch_one<0, 1>(g, grid, st);
     } else if (g.diag_skip == 2) {
         if (g.accumulate) launch_one<1, 2>(g, grid, st); else launch_one<0, 2>(g, grid, st);
+    } else if (g.fuse && g.accumulate) {
+        launch_one<1, 0, 1>(g, grid, st);
     } else {
         if (g.accumulate) launch_one<1, 0>(g, grid, st); else launch_one<0, 0>(g, grid, st);
     }
