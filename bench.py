@@ -213,7 +213,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
                                "traffic_note": "bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_tile_gemm.md",
-                               "kernel": "tile_gemm_nt_kernel<1> (f64 MFMA tile update)",
+                               "kernel": "tile_gemm_nt_kernel<1, 0, *> (f64 MFMA tile update: trailing updates + fused in-panel column update / panel solve)",
                                "launches": int(launches), "avg_launch_ms": kms / launches,
                                "algorithmic_flop_per_launch": kflop / launches,
                                "share_of_step_time": kms * 1e-3 / dt}
