@@ -72,6 +72,7 @@ SIGNATURES = {
     "gpslc_last_info": (C.c_int, [C.c_void_p, c_int32_p, C.c_int64]),
     "gpslc_profile_reset": (C.c_int, [C.c_void_p]),
     "gpslc_profile_get": (C.c_int, [C.c_void_p, c_int64_p, c_double_p, c_double_p]),
+    "gpslc_profile_get_class": (C.c_int, [C.c_void_p, C.c_int32, c_int64_p, c_double_p, c_double_p]),
     "gpslc_version": (C.c_char_p, []),
 }
 

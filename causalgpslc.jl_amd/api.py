@@ -91,11 +91,13 @@ class Context:
     def profile_reset(self):
         self.lib.gpslc_profile_reset(self.h)
 
-    def profile_get(self):
+    def profile_get(self, kernel_class=0):
+        """(launches, ms, algorithmic flop) of the tile-update kernel; class 0 = trailing updates (the dominant
+        kernel), 1 = the fused in-panel launches."""
         n = C.c_int64()
         ms = C.c_double()
         fl = C.c_double()
-        self.lib.gpslc_profile_get(self.h, C.byref(n), C.byref(ms), C.byref(fl))
+        self.lib.gpslc_profile_get_class(self.h, int(kernel_class), C.byref(n), C.byref(ms), C.byref(fl))
         return n.value, ms.value, fl.value
 
 

@@ -44,6 +44,7 @@ struct Arena {
 struct ProfRec {
     hipEvent_t a, b;
     double flop;
+    int cls;     // 0: tile_gemm_nt_kernel<1, 0, 0> (trailing updates, SYRKs), 1: <1, 0, 1> (fused in-panel launches)
 };
 
 }  // namespace
@@ -77,8 +78,8 @@ struct gpslc_ctx {
     // profiling of the dominant kernel
     std::vector<ProfRec> prof;
     size_t prof_used = 0;
-    int64_t prof_launches = 0;
-    double prof_ms = 0.0, prof_flop = 0.0;
+    int64_t prof_launches[2] = {0, 0};     // per kernel class, see ProfRec::cls
+    double prof_ms[2] = {0.0, 0.0}, prof_flop[2] = {0.0, 0.0};
 };
 
 namespace {
@@ -230,6 +231,7 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
         // fused panel product: one triangular solve per tile row = 128^2 * 128 multiply-adds... counted as the
         // textbook n^2 b flop of a TRSM (the kernel runs 56 % of the dense 2*128^3 product)
         if (g.fuse) r.flop += (double)GP_TS * GP_TS * rows * (double)g.nbatch;
+        r.cls = g.fuse ? 1 : 0;
         HC(hipEventRecord(r.a, st));
         launch_tile_gemm(g, st);
         HC(hipEventRecord(r.b, st));
@@ -252,9 +254,10 @@ void prof_collect(gpslc_ctx* c) {
     for (size_t i = 0; i < c->prof_used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->prof[i].a, c->prof[i].b) == hipSuccess) {
-            c->prof_ms += ms;
-            c->prof_flop += c->prof[i].flop;
-            c->prof_launches += 1;
+            const int k = c->prof[i].cls;
+            c->prof_ms[k] += ms;
+            c->prof_flop[k] += c->prof[i].flop;
+            c->prof_launches[k] += 1;
         }
     }
     c->prof_used = 0;
@@ -1197,15 +1200,20 @@ int gpslc_last_info(const gpslc_ctx* c, int32_t* info, int64_t S) {
 
 int gpslc_profile_reset(gpslc_ctx* c) {
     if (!c) return -1;
-    c->prof_launches = 0; c->prof_ms = 0; c->prof_flop = 0; c->prof_used = 0;
+    for (int k = 0; k < 2; ++k) { c->prof_launches[k] = 0; c->prof_ms[k] = 0; c->prof_flop[k] = 0; }
+    c->prof_used = 0;
+    return GPSLC_OK;
+}
+int gpslc_profile_get_class(gpslc_ctx* c, int32_t cls, int64_t* launches, double* total_ms, double* total_flop) {
+    if (!c) return -1;
+    if (cls < 0 || cls > 1) return bad_arg(c, 2, "kernel class must be 0 or 1");
+    if (launches) *launches = c->prof_launches[cls];
+    if (total_ms) *total_ms = c->prof_ms[cls];
+    if (total_flop) *total_flop = c->prof_flop[cls];
     return GPSLC_OK;
 }
 int gpslc_profile_get(gpslc_ctx* c, int64_t* launches, double* total_ms, double* total_flop) {
-    if (!c) return -1;
-    if (launches) *launches = c->prof_launches;
-    if (total_ms) *total_ms = c->prof_ms;
-    if (total_flop) *total_flop = c->prof_flop;
-    return GPSLC_OK;
+    return gpslc_profile_get_class(c, 0, launches, total_ms, total_flop);
 }
 
 }  // extern "C"

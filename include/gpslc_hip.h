@@ -179,11 +179,15 @@ int gpslc_last_info(const gpslc_ctx* ctx, int32_t* info, int64_t S);
 
 /* ---- measurement hooks (bench.py, profiles/) ----------------------------------------- */
 
-/* Accumulated HIP-event statistics of the dominant kernel (the f64-MFMA tile update) since
- * the last reset, recorded when the ctx was created with GPSLC_FLAG_PROFILE:
- * launches, total device milliseconds, total algorithmic flop. */
+/* Accumulated HIP-event statistics of the f64-MFMA tile-update kernel since the last reset, recorded when
+ * the ctx was created with GPSLC_FLAG_PROFILE: launches, total device milliseconds, total algorithmic flop.
+ * Kernel class 0 = tile_gemm_nt_kernel<1, 0, 0> (trailing updates and SYRKs: the dominant kernel),
+ * class 1 = tile_gemm_nt_kernel<1, 0, 1> (in-panel column update fused with the panel solve).
+ * gpslc_profile_get is class 0. */
 int gpslc_profile_reset(gpslc_ctx* ctx);
 int gpslc_profile_get(gpslc_ctx* ctx, int64_t* launches, double* total_ms, double* total_flop);
+int gpslc_profile_get_class(gpslc_ctx* ctx, int32_t kernel_class, int64_t* launches, double* total_ms,
+                            double* total_flop);
 
 /* library / build identification, e.g. "gpslc_hip 0.1 gfx950" */
 const char* gpslc_version(void);
