@@ -180,6 +180,12 @@ def main():
         dt = float(tt.item())
     launches, kms, kflop = ctx.profile_get(0)      # tile_gemm_nt_kernel<1, 0, 0>: the dominant kernel
     launches1, kms1, kflop1 = ctx.profile_get(1)   # <1, 0, 1>: in-panel column update fused with the panel solve
+    kname = "tile_gemm_nt_kernel<1, 0, 0> (f64 MFMA tile update: trailing updates of the blocked Cholesky)"
+    kname1 = "tile_gemm_nt_kernel<1, 0, 1> (f64 MFMA tile update: in-panel column update fused with the panel solve)"
+    if kms1 > kms:
+        # small N (at most one panel of tile columns): the in-panel instantiation is the dominant kernel
+        launches, kms, kflop, launches1, kms1, kflop1 = launches1, kms1, kflop1, launches, kms, kflop
+        kname, kname1 = kname1, kname
 
     if rank == 0:
         total_samples = Sr * world * a.steps
@@ -214,13 +220,13 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
                                "traffic_note": "bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_tile_gemm.md",
-                               "kernel": "tile_gemm_nt_kernel<1, 0, 0> (f64 MFMA tile update: trailing updates of the blocked Cholesky)",
+                               "kernel": kname,
                                "launches": int(launches), "avg_launch_ms": kms / launches,
                                "algorithmic_flop_per_launch": kflop / launches,
                                "share_of_step_time": kms * 1e-3 / dt}
             if launches1 > 0 and kms1 > 0:
                 out["roofline"]["second_kernel"] = {
-                    "kernel": "tile_gemm_nt_kernel<1, 0, 1> (in-panel column update fused with the panel solve)",
+                    "kernel": kname1,
                     "achieved": kflop1 / (kms1 * 1e-3) / 1e12, "frac": kflop1 / (kms1 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                     "launches": int(launches1), "avg_launch_ms": kms1 / launches1,
                     "share_of_step_time": kms1 * 1e-3 / dt}
