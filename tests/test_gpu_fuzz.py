@@ -74,3 +74,23 @@ def test_wide_feature_counts(gp, nU, nX, L, binary):
         for l in range(L):
             m, _ = orc.structured_ite(p, X, T, Y, doTs[l])
             assert np.max(np.abs(mi[:, s, l] - m)) <= 1e-9 * np.max(np.abs(m)) + 1e-13
+
+
+def test_results_are_bitwise_reproducible(gp):
+    """The persistent workgroups take their tiles from ticket counters, so WHICH workgroup computes a tile varies
+    from run to run — the arithmetic of a tile does not: two runs of the same call must agree to the last bit."""
+    rng = np.random.default_rng(99)
+    n, nU, nX, S, L = 700, 2, 5, 24, 3
+    X = rng.standard_normal((n, nX))
+    T = rng.standard_normal(n)
+    Y = rng.standard_normal(n)
+    ig = lambda size: np.maximum(4.0 / rng.gamma(4.0, 1.0, size=size), 0.4)   # noqa: E731
+    g = gp.GPSLCObject(X, T, Y, rng.standard_normal((n, nU, S)), ig((nU, S)), ig((nX, S)), ig(S), ig(S), ig(S))
+    doTs = np.array([-0.5, 0.1, 0.8])
+    a = gp.predict(g, doTs, want_mean_ite=True)
+    for _ in range(3):
+        b = gp.predict(g, doTs, want_mean_ite=True)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    lp1, lp2 = gp.yLogpdf(g), gp.yLogpdf(g)
+    assert np.array_equal(lp1, lp2)
