@@ -7,7 +7,7 @@ The directory name carries a dot, so it is imported through the repo-root shim
 from ._lib import GPSLCError, GPSLCLibraryError, PosDefException, load as load_library  # noqa: F401
 from .api import (  # noqa: F401
     Context, GPSLCObject, HyperParameters, PREDICTION_COVARIANCE_NOISE,
-    rbfKernelLog, processCov, likelihoodDistribution, extractParameters, conditionalITE, ITEDistributions, ITEsamples, conditionalSATE,
+    rbfKernelLog, rbfKernelLogScalar, logit, expit, processCov, likelihoodDistribution, extractParameters, conditionalITE, ITEDistributions, ITEsamples, conditionalSATE,
     SATEDistributions, SATEsamples, sampleITE, sampleSATE, predictCounterfactualEffects,
     summarizeEstimates, yLogpdf, gpLogpdf, mvnLogpdf, predict, doTRange, getN, getNX, getNU, getNumPosteriorSamples,
 )

@@ -54,8 +54,10 @@ SIGNATURES = {
     "gpslc_set_tuning": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "gpslc_last_error": (C.c_char_p, [C.c_void_p]),
     "gpslc_rbf_log": (C.c_int, [C.c_void_p, _D, _D, C.c_int64, C.c_int32, _D, C.c_int32, _D]),
+    "gpslc_rbf_log_dev": (C.c_int, [C.c_void_p, _D, _D, C.c_int64, C.c_int32, _D, C.c_int32, _D]),
     "gpslc_process_cov": (C.c_int, [C.c_void_p, _D, C.c_int64, C.c_double, C.c_double, _D]),
-    "gpslc_y_logpdf": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D, _D, _D, _D, _D]),
+    "gpslc_process_cov_dev": (C.c_int, [C.c_void_p, _D, C.c_int64, C.c_double, C.c_double, _D]),
+    "gpslc_y_logpdf": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D, _D, _D, _D, _D, _D]),
     "gpslc_gp_logpdf": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _D, C.c_int32, _D, _D, _D, _D, C.c_int32, _D]),
     "gpslc_mvn_logpdf": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D]),
     "gpslc_predict": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D, _D, _D, C.c_int32, _D, C.c_double,
@@ -74,7 +76,16 @@ SIGNATURES = {
     "gpslc_profile_get": (C.c_int, [C.c_void_p, c_int64_p, c_double_p, c_double_p]),
     "gpslc_profile_get_class": (C.c_int, [C.c_void_p, C.c_int32, c_int64_p, c_double_p, c_double_p]),
     "gpslc_version": (C.c_char_p, []),
+    "gpslc_pack_save": (C.c_int, [C.c_char_p, C.c_void_p, _D, _D, _D, _D, _D, _D, _D, _D, _D]),
+    "gpslc_pack_read_header": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "gpslc_pack_load": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, _D, _D, _D, _D, _D, _D, _D, _D, _D]),
 }
+
+
+class PackHeader(C.Structure):
+    """gpslc_pack_header (include/gpslc_hip.h)."""
+    _fields_ = [("n", C.c_int64), ("nX", C.c_int64), ("nU", C.c_int64), ("S", C.c_int64),
+                ("binary_t", C.c_int64), ("reserved", C.c_int64), ("hyper", C.c_double * 7)]
 
 _lib = None
 

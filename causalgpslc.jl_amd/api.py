@@ -136,6 +136,27 @@ def rbfKernelLog(X1, X2, LS):
     return out
 
 
+def rbfKernelLogScalar(Xi, Xiprime, LS):
+    """rbfKernelLogScalar(Xi, Xiprime, LS) = -sum((Xi - Xiprime)^2 / LS^2) for one pair of individuals
+    (src/kernel.jl:13-19), evaluated by the same device kernel as the matrix form (n = 1)."""
+    a = np.atleast_1d(np.asarray(Xi, dtype=np.float64))
+    b = np.atleast_1d(np.asarray(Xiprime, dtype=np.float64))
+    ls = np.asarray(LS, dtype=np.float64)
+    if not (ls.shape == () or ls.shape[0] == a.shape[0]):
+        raise AssertionError("vector lengthscale doesn't match individual")
+    return float(rbfKernelLog(a[None, :], b[None, :], ls)[0, 0])
+
+
+def logit(prob):
+    """logit(prob) = log(prob / (1 - prob)) (src/kernel.jl:46)."""
+    return float(np.log(prob / (1 - prob)))
+
+
+def expit(x):
+    """expit(x) = exp(x) / (1 + exp(x)) (src/kernel.jl:49)."""
+    return float(np.exp(x) / (1.0 + np.exp(x)))
+
+
 def processCov(logCov, scale, noise=None):
     """processCov(logCov, scale[, noise]) (src/kernel.jl:53-59)."""
     lc = _f(np.atleast_2d(logCov))
@@ -438,15 +459,17 @@ def summarizeEstimates(samples, credible_interval=0.90):
 # src/model_likelihood.jl :Y node
 # ------------------------------------------------------------------------------------------
 
-def yLogpdf(g: GPSLCObject, X_override=None):
-    """log N(Y; 0, Ycov) for every parameter set of ``g`` (the score the :Y address contributes to a
-    Gen trace; src/model_likelihood.jl:83-120)."""
+def yLogpdf(g: GPSLCObject, X_override=None, Y_override=None):
+    """log N(y; 0, Ycov) for every parameter set of ``g`` (the score the :Y address contributes to a
+    Gen trace; src/model_likelihood.jl:83-120).  ``y`` is ``Y_override`` when given (the value Gen hands to a
+    distribution's logpdf), else the data Y the node is constrained to."""
     S = g.getNumPosteriorSamples()
     ctx = g.ctx()
     out = np.empty(S)
     Xo = None if X_override is None else _f(X_override).reshape(g.getN(), g.getNX(), order="F")
+    Yo = None if Y_override is None else _f(Y_override, (g.getN(),))
     U, uy, xy, ty, ys, yn = g._params()
-    st = ctx.lib.gpslc_y_logpdf(ctx.h, S, U, _p(Xo), uy, xy, ty, ys, yn, _p(out))
+    st = ctx.lib.gpslc_y_logpdf(ctx.h, S, U, _p(Xo), _p(Yo), uy, xy, ty, ys, yn, _p(out))
     ctx.check(st)
     return out
 

@@ -41,6 +41,57 @@ struct Arena {
     }
 };
 
+// Growable device staging pool of a ctx (host-pointer entry points: uploads, outputs, info words).  take() never
+// moves earlier allocations: when the current block is full a new one is chained; the next reset() merges the
+// chain into one block of the total size, so a steady-state call sequence allocates nothing.
+struct PoolArena {
+    struct Block { char* base; size_t bytes; };
+    std::vector<Block> blocks;
+    size_t off = 0;
+    void release() {
+        for (auto& b : blocks) (void)hipFree(b.base);
+        blocks.clear();
+        off = 0;
+    }
+    void reset() {
+        if (blocks.size() > 1) {
+            size_t total = 0;
+            for (auto& b : blocks) total += b.bytes;
+            (void)hipDeviceSynchronize();
+            release();
+            add_block(total);
+        }
+        off = 0;
+    }
+    void add_block(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); throw std::bad_alloc(); }
+        blocks.push_back(Block{static_cast<char*>(p), bytes});
+        off = 0;
+    }
+    template <class T>
+    T* take(size_t count) {
+        const size_t need = std::max<size_t>(count * sizeof(T), 8);
+        size_t a = (off + 255) & ~size_t(255);
+        if (blocks.empty() || a + need > blocks.back().bytes) {
+            add_block(std::max<size_t>((need + 255) & ~size_t(255), size_t(1) << 20));
+            a = 0;
+        }
+        off = a + need;
+        return reinterpret_cast<T*>(blocks.back().base + a);
+    }
+};
+
+struct DevBuf {   // RAII device allocation for the host-pointer entry points
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void alloc(size_t bytes) {
+        if (bytes == 0) bytes = 8;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; throw std::bad_alloc(); }
+    }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
 struct ProfRec {
     hipEvent_t a, b;
     double flop;
@@ -64,7 +115,8 @@ struct gpslc_ctx {
     std::vector<hipStream_t> streams;
     std::vector<Arena> arenas;     // one per stream slot
     std::vector<int*> queues;      // one ticket-counter block (16 ints) per stream slot, see GemmArgs::queue
-    Arena scratch;                 // call-level buffers (host-pointer entry points, info, ...)
+    Arena scratch;                 // call-level buffers (internal MeanITE of a draws-only call, ...)
+    PoolArena io;                  // staging of the host-pointer entry points and per-call info words
     std::string err;
     std::vector<int32_t> last_info;
     // cached factor of the last dense covariance given to gpslc_mvn_logpdf (SigmaU is constant per data set)
@@ -133,19 +185,19 @@ void ensure_streams(gpslc_ctx* c) {
 // ---- profiled launch of the accumulate-mode tile kernel ---------------------------------
 // GPSLC_SYRK_DIAG=0 keeps the diagonal tiles in the general kernel (A/B switch for measurements)
 static int sym_mode() {
-    static const int m = [] { const char* e = getenv("GPSLC_SYRK_DIAG"); return (e && atoi(e) == 0) ? 1 : 2; }();
+    static const int m = diag_env("GPSLC_SYRK_DIAG", 1) == 0 ? 1 : 2;
     return m;
 }
 
 static int col_sym_mode() {
     // the one diagonal tile of an in-panel column update also goes to the lower-triangle kernel (+0.2 %, measured)
-    static const int m = [] { const char* e = getenv("GPSLC_SYRK_DIAG_COL"); return (e && atoi(e) == 0) ? 1 : sym_mode(); }();
+    static const int m = diag_env("GPSLC_SYRK_DIAG_COL", 1) == 0 ? 1 : sym_mode();
     return m;
 }
 
 // with a single short augmented tile row, its off-diagonal tiles ride with the diagonal items (GemmArgs::sym == 3)
 static int aug_sym(int sym, int short_rows) {
-    static const int on = [] { const char* e = getenv("GPSLC_SYRK_AUG"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    static const int on = diag_env("GPSLC_SYRK_AUG", 1) == 0 ? 0 : 1;
     // up to 32 live rows (31 levels): beyond that the diagonal kernel runs out of registers and the augmented
     // tiles carry enough real work to stay ordinary items
     return (sym == 2 && short_rows > 0 && short_rows <= 32 && on) ? 3 : sym;
@@ -153,7 +205,7 @@ static int aug_sym(int sym, int short_rows) {
 
 // GPSLC_FUSE_PANEL=0: separate panel-product launches for every column (measurement switch)
 static int fuse_mode() {
-    static const int m = [] { const char* e = getenv("GPSLC_FUSE_PANEL"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    static const int m = diag_env("GPSLC_FUSE_PANEL", 1) == 0 ? 0 : 1;
     return m;
 }
 
@@ -167,25 +219,31 @@ static void launch_sym_diag_tiles(const GemmArgs& g, hipStream_t st) {
 
 void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
     GemmArgs g = g0;
-    static const int diag_skip = getenv("GPSLC_GEMM_DIAG") ? atoi(getenv("GPSLC_GEMM_DIAG")) : 0;
-    g.diag_skip = diag_skip;   // timing-only diagnostic, results are garbage when set
-    static const int use_queue = getenv("GPSLC_GEMM_QUEUE") ? atoi(getenv("GPSLC_GEMM_QUEUE")) : 1;
+    g.diag_skip = 0;
+    g.dbg = nullptr;
+    static const int use_queue = diag_env("GPSLC_GEMM_QUEUE", 1);
     g.queue = nullptr;
     if (use_queue)
         for (size_t i = 0; i < c->streams.size() && i < c->queues.size(); ++i)
             if (c->streams[i] == st) g.queue = c->queues[i];
-    static const int dbg_m = getenv("GPSLC_GEMM_DBG") ? atoi(getenv("GPSLC_GEMM_DBG")) : 0;
+    if (g.ntiles <= 0 || g.nbatch <= 0 || (g.k1 <= g.k0 && g.accumulate)) return;
+#ifdef GPSLC_DIAG
+    // measurement build only: timing-only kernel variants (results are garbage by construction) and in-kernel
+    // stamps of one trailing update, written to gpurun_out/gemm_dbg.bin
+    static const int diag_skip = diag_env("GPSLC_GEMM_DIAG", 0);
+    g.diag_skip = diag_skip;
+    static const int dbg_m = diag_env("GPSLC_GEMM_DBG", 0);
     static bool dbg_done = false;
-    unsigned long long* dbg_buf = nullptr;
+    DevBuf dbg_buf;
     size_t dbg_words = 0;
     if (dbg_m > 0 && !dbg_done && g.shape == 0 && g.mi == dbg_m) {
         dbg_words = (size_t)g.ntiles * g.nbatch * 8;
-        HC(hipMalloc((void**)&dbg_buf, dbg_words * 8));
-        HC(hipMemset(dbg_buf, 0, dbg_words * 8));
-        g.dbg = dbg_buf;
+        dbg_buf.alloc(dbg_words * 8);
+        HC(hipMemset(dbg_buf.p, 0, dbg_words * 8));
+        g.dbg = dbg_buf.as<unsigned long long>();
         dbg_done = true;
     }
-    if (g.ntiles <= 0 || g.nbatch <= 0 || (g.k1 <= g.k0 && g.accumulate)) return;
+#endif
     // sym == 2: the full-size diagonal tiles (those above the augmented rows) go to the lower-triangle kernel
     auto launch_diag_tiles = [&]() {
         if (g.fuse) return;     // potrf_tiles launched them before the diagonal-block kernel (launch_sym_diag_tiles)
@@ -240,14 +298,16 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
         launch_tile_gemm(g, st);
         launch_diag_tiles();
     }
-    if (dbg_buf) {
+    HC(hipGetLastError());   // launch-configuration errors (LDS opt-in, grid) surface here, not at the end of the call
+#ifdef GPSLC_DIAG
+    if (dbg_buf.p) {
         HC(hipStreamSynchronize(st));
         std::vector<unsigned long long> h(dbg_words);
-        HC(hipMemcpy(h.data(), dbg_buf, dbg_words * 8, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(h.data(), dbg_buf.p, dbg_words * 8, hipMemcpyDeviceToHost));
         FILE* f = fopen("gpurun_out/gemm_dbg.bin", "wb");
         if (f) { fwrite(h.data(), 8, dbg_words, f); fclose(f); }
-        (void)hipFree(dbg_buf);
     }
+#endif
 }
 
 void prof_collect(gpslc_ctx* c) {
@@ -625,20 +685,16 @@ double philox_normal_host(uint64_t seed, uint64_t stream, uint64_t e) {
     return (e & 1) ? rad * std::sin(ang) : rad * std::cos(ang);
 }
 
-struct DevBuf {   // RAII device allocation for the host-pointer entry points
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    void alloc(size_t bytes) {
-        if (bytes == 0) bytes = 8;
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; throw std::bad_alloc(); }
-    }
-    template <class T> T* as() { return static_cast<T*>(p); }
-};
-
 double* up(DevBuf& b, const double* host, size_t count) {
     b.alloc(count * sizeof(double));
     if (count) HC(hipMemcpy(b.p, host, count * sizeof(double), hipMemcpyHostToDevice));
     return b.as<double>();
+}
+// upload into the ctx's staging pool (no allocation in steady state)
+double* up(gpslc_ctx* c, const double* host, size_t count) {
+    double* d = c->io.take<double>(count);
+    if (count) HC(hipMemcpy(d, host, count * sizeof(double), hipMemcpyHostToDevice));
+    return d;
 }
 
 int check_common(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,
@@ -672,7 +728,7 @@ int gpslc_create(gpslc_ctx** out, int device, int64_t n, int32_t nX, int32_t nU,
     if (!c) return GPSLC_ERR_NOMEM;
     c->device = device; c->n = n; c->nX = nX; c->nU = nU; c->flags = flags;
     c->nt = (int)((n + GP_TS - 1) / GP_TS);
-    if (getenv("GPSLC_ORDER_BLOCK")) c->order_block = atoi(getenv("GPSLC_ORDER_BLOCK"));
+    c->order_block = diag_env("GPSLC_ORDER_BLOCK", c->order_block);
     int rc = guarded(c, [&]() {
         hipDeviceProp_t prop;
         HC(hipGetDeviceProperties(&prop, device));
@@ -683,6 +739,11 @@ int gpslc_create(gpslc_ctx** out, int device, int64_t n, int32_t nX, int32_t nU,
         HC(hipMalloc((void**)&c->dX, sizeof(double) * std::max<int64_t>(1, n * nX)));
         HC(hipMalloc((void**)&c->dT, sizeof(double) * n));
         HC(hipMalloc((void**)&c->dY, sizeof(double) * n));
+        // defined contents before gpslc_set_data: the node-score entry points that bring their own features and
+        // target (gpslc_gp_logpdf, gpslc_mvn_logpdf) work on a ctx without data
+        HC(hipMemset(c->dX, 0, sizeof(double) * std::max<int64_t>(1, n * nX)));
+        HC(hipMemset(c->dT, 0, sizeof(double) * n));
+        HC(hipMemset(c->dY, 0, sizeof(double) * n));
         ensure_streams(c);
         return GPSLC_OK;
     });
@@ -699,6 +760,7 @@ int gpslc_destroy(gpslc_ctx* c) {
     for (auto& a : c->arenas) if (a.base) (void)hipFree(a.base);
     for (int* q : c->queues) if (q) (void)hipFree(q);
     if (c->scratch.base) (void)hipFree(c->scratch.base);
+    c->io.release();
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto p : c->tri_order) if (p) (void)hipFree(p);
     if (c->mvn_tiles) (void)hipFree(c->mvn_tiles);
@@ -747,8 +809,8 @@ int gpslc_set_tuning(gpslc_ctx* c, int32_t max_batch, int32_t panel_tiles, int32
 
 const char* gpslc_last_error(const gpslc_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
-int gpslc_rbf_log(gpslc_ctx* c, const double* X1, const double* X2, int64_t n, int32_t d, const double* ls,
-                  int32_t ls_len, double* out) {
+static int rbf_log_check(gpslc_ctx* c, const double* X1, const double* X2, int64_t n, int32_t d, const double* ls,
+                         int32_t ls_len, double* out) {
     if (!c) return -1;
     if (!X1) return bad_arg(c, 2, "X1 is NULL");
     if (!X2) return bad_arg(c, 3, "X2 is NULL");
@@ -757,17 +819,51 @@ int gpslc_rbf_log(gpslc_ctx* c, const double* X1, const double* X2, int64_t n, i
     if (!ls) return bad_arg(c, 6, "ls is NULL");
     if (ls_len != 1 && ls_len != d) return bad_arg(c, 7, "vector lengthscale doesn't match individual");
     if (!out) return bad_arg(c, 8, "out is NULL");
+    return 0;
+}
+
+int gpslc_rbf_log_dev(gpslc_ctx* c, const double* X1, const double* X2, int64_t n, int32_t d, const double* ls,
+                      int32_t ls_len, double* out) {
+    int rc = rbf_log_check(c, X1, X2, n, d, ls, ls_len, out);
+    if (rc) return rc;
     return guarded(c, [&]() {
         ensure_streams(c);
-        DevBuf a, b, l, o;
-        double* dA = up(a, X1, (size_t)n * d);
-        double* dB = up(b, X2, (size_t)n * d);
-        double* dl = up(l, ls, (size_t)ls_len);
-        o.alloc(sizeof(double) * n * n);
-        launch_rbf_log(dA, dB, n, d, dl, ls_len, o.as<double>(), c->streams[0]);
-        HC(hipStreamSynchronize(c->streams[0]));
+        launch_rbf_log(X1, X2, n, d, ls, ls_len, out, c->streams[0]);
         HC(hipGetLastError());
-        HC(hipMemcpy(out, o.p, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+        HC(hipStreamSynchronize(c->streams[0]));
+        return GPSLC_OK;
+    });
+}
+
+int gpslc_rbf_log(gpslc_ctx* c, const double* X1, const double* X2, int64_t n, int32_t d, const double* ls,
+                  int32_t ls_len, double* out) {
+    int rc = rbf_log_check(c, X1, X2, n, d, ls, ls_len, out);
+    if (rc) return rc;
+    return guarded(c, [&]() {
+        ensure_streams(c);
+        c->io.reset();
+        double* dA = up(c, X1, (size_t)n * d);
+        double* dB = up(c, X2, (size_t)n * d);
+        double* dl = up(c, ls, (size_t)ls_len);
+        double* o = c->io.take<double>((size_t)n * n);
+        launch_rbf_log(dA, dB, n, d, dl, ls_len, o, c->streams[0]);
+        HC(hipGetLastError());
+        HC(hipStreamSynchronize(c->streams[0]));
+        HC(hipMemcpy(out, o, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+        return GPSLC_OK;
+    });
+}
+
+int gpslc_process_cov_dev(gpslc_ctx* c, const double* logcov, int64_t n, double scale, double noise, double* out) {
+    if (!c) return -1;
+    if (!logcov) return bad_arg(c, 2, "logcov is NULL");
+    if (n < 1) return bad_arg(c, 3, "n < 1");
+    if (!out) return bad_arg(c, 6, "out is NULL");
+    return guarded(c, [&]() {
+        ensure_streams(c);
+        launch_process_cov(logcov, n, scale, noise, out, c->streams[0]);
+        HC(hipGetLastError());
+        HC(hipStreamSynchronize(c->streams[0]));
         return GPSLC_OK;
     });
 }
@@ -779,37 +875,53 @@ int gpslc_process_cov(gpslc_ctx* c, const double* logcov, int64_t n, double scal
     if (!out) return bad_arg(c, 6, "out is NULL");
     return guarded(c, [&]() {
         ensure_streams(c);
-        DevBuf a, o;
-        double* dA = up(a, logcov, (size_t)n * n);
-        o.alloc(sizeof(double) * n * n);
-        launch_process_cov(dA, n, scale, noise, o.as<double>(), c->streams[0]);
-        HC(hipStreamSynchronize(c->streams[0]));
+        c->io.reset();
+        double* dA = up(c, logcov, (size_t)n * n);
+        double* o = c->io.take<double>((size_t)n * n);
+        launch_process_cov(dA, n, scale, noise, o, c->streams[0]);
         HC(hipGetLastError());
-        HC(hipMemcpy(out, o.p, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+        HC(hipStreamSynchronize(c->streams[0]));
+        HC(hipMemcpy(out, o, sizeof(double) * n * n, hipMemcpyDeviceToHost));
         return GPSLC_OK;
     });
+}
+
+static int predict_check(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,
+                         const double* tyLS, const double* yScale, const double* yNoise, int32_t L,
+                         const double* doT, int32_t spp, const double* ite_draws) {
+    int rc = check_common(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise);
+    if (rc) return rc;
+    if (L < 1) return bad_arg(c, 9, "L < 1");
+    if (!doT) return bad_arg(c, 10, "doT is NULL");
+    if (ite_draws && spp < 1) return bad_arg(c, 12, "spp < 1 with ite_draws requested");
+    return 0;
+}
+
+// device pointers everywhere; the info words come from the staging pool (the caller has reset it)
+static int predict_dev_inner(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,
+                             const double* tyLS, const double* yScale, const double* yNoise, int32_t L,
+                             const double* doT, double pred_noise, int32_t spp, uint64_t seed, const double* z,
+                             double* meanSATE, double* varSATE, double* meanITE, double* ite_draws) {
+    PredictIO io;
+    io.S = S; io.p = SampleParams{U, uyLS, xyLS, tyLS, yScale, yNoise}; io.X = c->dX;
+    io.L = L; io.doT = doT; io.pred_noise = pred_noise; io.spp = spp; io.seed = seed; io.z = z;
+    io.meanSATE = meanSATE; io.varSATE = varSATE; io.meanITE = meanITE; io.ite_draws = ite_draws;
+    io.info = c->io.take<int>((size_t)S);
+    run_predict(c, io);
+    return first_info(c);
 }
 
 int gpslc_predict_dev(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,
                       const double* tyLS, const double* yScale, const double* yNoise, int32_t L,
                       const double* doT, double pred_noise, int32_t spp, uint64_t seed, const double* z,
                       double* meanSATE, double* varSATE, double* meanITE, double* ite_draws) {
-    int rc = check_common(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise);
+    int rc = predict_check(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, spp, ite_draws);
     if (rc) return rc;
-    if (L < 1) return bad_arg(c, 9, "L < 1");
-    if (!doT) return bad_arg(c, 10, "doT is NULL");
-    if (ite_draws && spp < 1) return bad_arg(c, 12, "spp < 1 with ite_draws requested");
     if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
     return guarded(c, [&]() {
-        DevBuf info;
-        info.alloc(sizeof(int) * S);
-        PredictIO io;
-        io.S = S; io.p = SampleParams{U, uyLS, xyLS, tyLS, yScale, yNoise}; io.X = c->dX;
-        io.L = L; io.doT = doT; io.pred_noise = pred_noise; io.spp = spp; io.seed = seed; io.z = z;
-        io.meanSATE = meanSATE; io.varSATE = varSATE; io.meanITE = meanITE; io.ite_draws = ite_draws;
-        io.info = info.as<int>();
-        run_predict(c, io);
-        return first_info(c);
+        c->io.reset();
+        return predict_dev_inner(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, pred_noise, spp, seed, z,
+                                 meanSATE, varSATE, meanITE, ite_draws);
     });
 }
 
@@ -817,34 +929,31 @@ int gpslc_predict(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, 
                   const double* tyLS, const double* yScale, const double* yNoise, int32_t L, const double* doT,
                   double pred_noise, int32_t spp, uint64_t seed, const double* z, double* meanSATE,
                   double* varSATE, double* meanITE, double* ite_draws) {
-    int rc = check_common(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise);
+    int rc = predict_check(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, spp, ite_draws);
     if (rc) return rc;
-    if (L < 1) return bad_arg(c, 9, "L < 1");
-    if (!doT) return bad_arg(c, 10, "doT is NULL");
-    if (ite_draws && spp < 1) return bad_arg(c, 12, "spp < 1 with ite_draws requested");
     if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
     return guarded(c, [&]() {
         const size_t n = (size_t)c->n;
-        DevBuf bU, buy, bxy, bty, bys, byn, bdo, bz, oms, ovs, omi, odr;
-        const double* dU = c->nU ? up(bU, U, n * c->nU * S) : nullptr;
-        const double* duy = c->nU ? up(buy, uyLS, (size_t)c->nU * S) : nullptr;
-        const double* dxy = c->nX ? up(bxy, xyLS, (size_t)c->nX * S) : nullptr;
-        const double* dty = up(bty, tyLS, S);
-        const double* dys = up(bys, yScale, S);
-        const double* dyn = up(byn, yNoise, S);
-        const double* ddo = up(bdo, doT, L);
-        const double* dz = (z && ite_draws) ? up(bz, z, n * spp * S * L) : nullptr;
-        if (meanSATE) oms.alloc(sizeof(double) * S * L);
-        if (varSATE) ovs.alloc(sizeof(double) * S * L);
-        if (meanITE) omi.alloc(sizeof(double) * n * S * L);
-        if (ite_draws) odr.alloc(sizeof(double) * (size_t)L * n * S * spp);
-        int st = gpslc_predict_dev(c, S, dU, duy, dxy, dty, dys, dyn, L, ddo, pred_noise, spp, seed, dz,
-                                   oms.as<double>(), ovs.as<double>(), omi.as<double>(), odr.as<double>());
+        c->io.reset();
+        const double* dU = c->nU ? up(c, U, n * c->nU * S) : nullptr;
+        const double* duy = c->nU ? up(c, uyLS, (size_t)c->nU * S) : nullptr;
+        const double* dxy = c->nX ? up(c, xyLS, (size_t)c->nX * S) : nullptr;
+        const double* dty = up(c, tyLS, S);
+        const double* dys = up(c, yScale, S);
+        const double* dyn = up(c, yNoise, S);
+        const double* ddo = up(c, doT, L);
+        const double* dz = (z && ite_draws) ? up(c, z, n * spp * S * L) : nullptr;
+        double* oms = meanSATE ? c->io.take<double>((size_t)S * L) : nullptr;
+        double* ovs = varSATE ? c->io.take<double>((size_t)S * L) : nullptr;
+        double* omi = meanITE ? c->io.take<double>(n * S * L) : nullptr;
+        double* odr = ite_draws ? c->io.take<double>((size_t)L * n * S * spp) : nullptr;
+        int st = predict_dev_inner(c, S, dU, duy, dxy, dty, dys, dyn, L, ddo, pred_noise, spp, seed, dz,
+                                   oms, ovs, omi, odr);
         if (st < 0) return st;
-        if (meanSATE) HC(hipMemcpy(meanSATE, oms.p, sizeof(double) * S * L, hipMemcpyDeviceToHost));
-        if (varSATE) HC(hipMemcpy(varSATE, ovs.p, sizeof(double) * S * L, hipMemcpyDeviceToHost));
-        if (meanITE) HC(hipMemcpy(meanITE, omi.p, sizeof(double) * n * S * L, hipMemcpyDeviceToHost));
-        if (ite_draws) HC(hipMemcpy(ite_draws, odr.p, sizeof(double) * (size_t)L * n * S * spp, hipMemcpyDeviceToHost));
+        if (meanSATE) HC(hipMemcpy(meanSATE, oms, sizeof(double) * S * L, hipMemcpyDeviceToHost));
+        if (varSATE) HC(hipMemcpy(varSATE, ovs, sizeof(double) * S * L, hipMemcpyDeviceToHost));
+        if (meanITE) HC(hipMemcpy(meanITE, omi, sizeof(double) * n * S * L, hipMemcpyDeviceToHost));
+        if (ite_draws) HC(hipMemcpy(ite_draws, odr, sizeof(double) * (size_t)L * n * S * spp, hipMemcpyDeviceToHost));
         return st;
     });
 }
@@ -857,59 +966,64 @@ int gpslc_ite_distributions(gpslc_ctx* c, int64_t S, const double* U, const doub
     if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
     return guarded(c, [&]() {
         const size_t n = (size_t)c->n;
-        DevBuf bU, buy, bxy, bty, bys, byn, bdo, om, oc, info;
-        const double* dU = c->nU ? up(bU, U, n * c->nU * S) : nullptr;
-        const double* duy = c->nU ? up(buy, uyLS, (size_t)c->nU * S) : nullptr;
-        const double* dxy = c->nX ? up(bxy, xyLS, (size_t)c->nX * S) : nullptr;
-        const double* dty = up(bty, tyLS, S);
-        const double* dys = up(bys, yScale, S);
-        const double* dyn = up(byn, yNoise, S);
-        const double* ddo = up(bdo, &doT, 1);
-        if (MeanITEs) om.alloc(sizeof(double) * S * n);
-        if (CovITEs) oc.alloc(sizeof(double) * S * n * n);
-        info.alloc(sizeof(int) * S);
+        c->io.reset();
+        const double* dU = c->nU ? up(c, U, n * c->nU * S) : nullptr;
+        const double* duy = c->nU ? up(c, uyLS, (size_t)c->nU * S) : nullptr;
+        const double* dxy = c->nX ? up(c, xyLS, (size_t)c->nX * S) : nullptr;
+        const double* dty = up(c, tyLS, S);
+        const double* dys = up(c, yScale, S);
+        const double* dyn = up(c, yNoise, S);
+        const double* ddo = up(c, &doT, 1);
+        double* om = MeanITEs ? c->io.take<double>((size_t)S * n) : nullptr;
+        double* oc = CovITEs ? c->io.take<double>((size_t)S * n * n) : nullptr;
         PredictIO io;
         io.S = S; io.p = SampleParams{dU, duy, dxy, dty, dys, dyn}; io.X = c->dX;
         io.L = 1; io.doT = ddo; io.pred_noise = pred_noise;
-        io.MeanITEs = om.as<double>(); io.CovITEs = oc.as<double>(); io.info = info.as<int>();
+        io.MeanITEs = om; io.CovITEs = oc; io.info = c->io.take<int>((size_t)S);
         run_predict(c, io);
-        if (MeanITEs) HC(hipMemcpy(MeanITEs, om.p, sizeof(double) * S * n, hipMemcpyDeviceToHost));
-        if (CovITEs) HC(hipMemcpy(CovITEs, oc.p, sizeof(double) * S * n * n, hipMemcpyDeviceToHost));
+        if (MeanITEs) HC(hipMemcpy(MeanITEs, om, sizeof(double) * S * n, hipMemcpyDeviceToHost));
+        if (CovITEs) HC(hipMemcpy(CovITEs, oc, sizeof(double) * S * n * n, hipMemcpyDeviceToHost));
         return first_info(c);
     });
 }
 
-int gpslc_y_logpdf(gpslc_ctx* c, int64_t S, const double* U, const double* X_or_null, const double* uyLS,
-                   const double* xyLS, const double* tyLS, const double* yScale, const double* yNoise,
-                   double* logpdf) {
+// logpdf[s] = -(n log 2pi + logdet_s + quad_s) / 2 from the device-side epilogue values
+static void finish_logpdf(gpslc_ctx* c, int64_t S, const double* d_logdet, const double* d_quad, double* logpdf) {
+    std::vector<double> ld(S), q(S);
+    HC(hipMemcpy(ld.data(), d_logdet, sizeof(double) * S, hipMemcpyDeviceToHost));
+    HC(hipMemcpy(q.data(), d_quad, sizeof(double) * S, hipMemcpyDeviceToHost));
+    const double l2pi = 1.8378770664093454835606594728112;
+    for (int64_t s = 0; s < S; ++s) logpdf[s] = -0.5 * ((double)c->n * l2pi + ld[s] + q[s]);
+}
+
+int gpslc_y_logpdf(gpslc_ctx* c, int64_t S, const double* U, const double* X_or_null, const double* Y_or_null,
+                   const double* uyLS, const double* xyLS, const double* tyLS, const double* yScale,
+                   const double* yNoise, double* logpdf) {
     int rc = check_common(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise);
     if (rc) return rc;
-    if (!logpdf) return bad_arg(c, 10, "logpdf is NULL");
+    if (!logpdf) return bad_arg(c, 11, "logpdf is NULL");
     if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
     return guarded(c, [&]() {
         const size_t n = (size_t)c->n;
-        DevBuf bU, bX, buy, bxy, bty, bys, byn, bdo, old, oq, info;
-        const double* dU = c->nU ? up(bU, U, n * c->nU * S) : nullptr;
-        const double* dX = (X_or_null && c->nX) ? up(bX, X_or_null, n * c->nX) : c->dX;
-        const double* duy = c->nU ? up(buy, uyLS, (size_t)c->nU * S) : nullptr;
-        const double* dxy = c->nX ? up(bxy, xyLS, (size_t)c->nX * S) : nullptr;
-        const double* dty = up(bty, tyLS, S);
-        const double* dys = up(bys, yScale, S);
-        const double* dyn = up(byn, yNoise, S);
+        c->io.reset();
+        const double* dU = c->nU ? up(c, U, n * c->nU * S) : nullptr;
+        const double* dX = (X_or_null && c->nX) ? up(c, X_or_null, n * c->nX) : c->dX;
+        const double* dYo = Y_or_null ? up(c, Y_or_null, n) : nullptr;
+        const double* duy = c->nU ? up(c, uyLS, (size_t)c->nU * S) : nullptr;
+        const double* dxy = c->nX ? up(c, xyLS, (size_t)c->nX * S) : nullptr;
+        const double* dty = up(c, tyLS, S);
+        const double* dys = up(c, yScale, S);
+        const double* dyn = up(c, yNoise, S);
         const double zero = 0.0;
-        const double* ddo = up(bdo, &zero, 1);
-        old.alloc(sizeof(double) * S);
-        oq.alloc(sizeof(double) * S);
-        info.alloc(sizeof(int) * S);
+        const double* ddo = up(c, &zero, 1);
+        double* old = c->io.take<double>((size_t)S);
+        double* oq = c->io.take<double>((size_t)S);
         PredictIO io;
         io.S = S; io.p = SampleParams{dU, duy, dxy, dty, dys, dyn}; io.X = dX;
-        io.L = 0; io.doT = ddo; io.logdet = old.as<double>(); io.quad = oq.as<double>(); io.info = info.as<int>();
+        if (dYo) { io.Y = dYo; io.y_sstride = 0; }    // the value being scored (Gen passes it to logpdf), else the ctx's Y
+        io.L = 0; io.doT = ddo; io.logdet = old; io.quad = oq; io.info = c->io.take<int>((size_t)S);
         run_predict(c, io);
-        std::vector<double> ld(S), q(S);
-        HC(hipMemcpy(ld.data(), old.p, sizeof(double) * S, hipMemcpyDeviceToHost));
-        HC(hipMemcpy(q.data(), oq.p, sizeof(double) * S, hipMemcpyDeviceToHost));
-        const double l2pi = 1.8378770664093454835606594728112;
-        for (int64_t s = 0; s < S; ++s) logpdf[s] = -0.5 * ((double)c->n * l2pi + ld[s] + q[s]);
+        finish_logpdf(c, S, old, oq, logpdf);
         return first_info(c);
     });
 }
@@ -927,32 +1041,27 @@ int gpslc_gp_logpdf(gpslc_ctx* c, int64_t S, int32_t nF, const double* F, int32_
     if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
     return guarded(c, [&]() {
         const size_t n = (size_t)c->n;
-        DevBuf bF, bls, bsc, bno, btg, bty, bdo, old, oq, info;
-        const double* dF = nF ? up(bF, F, n * nF * (f_shared ? 1 : S)) : nullptr;
-        const double* dls = nF ? up(bls, ls, (size_t)nF * S) : nullptr;
-        const double* dsc = up(bsc, scale, S);
-        const double* dno = up(bno, noise, S);
-        const double* dtg = up(btg, target, n * (t_shared ? 1 : S));
+        c->io.reset();
+        const double* dF = nF ? up(c, F, n * nF * (f_shared ? 1 : S)) : nullptr;
+        const double* dls = nF ? up(c, ls, (size_t)nF * S) : nullptr;
+        const double* dsc = up(c, scale, S);
+        const double* dno = up(c, noise, S);
+        const double* dtg = up(c, target, n * (t_shared ? 1 : S));
         std::vector<double> inf(S, INFINITY);        // tyLS = inf switches the treatment term off: e_ij = exp(-0) = 1
-        const double* dty = up(bty, inf.data(), S);
+        const double* dty = up(c, inf.data(), S);
         const double zero = 0.0;
-        const double* ddo = up(bdo, &zero, 1);
-        old.alloc(sizeof(double) * S);
-        oq.alloc(sizeof(double) * S);
-        info.alloc(sizeof(int) * S);
+        const double* ddo = up(c, &zero, 1);
+        double* old = c->io.take<double>((size_t)S);
+        double* oq = c->io.take<double>((size_t)S);
         PredictIO io;
         io.S = S;
         io.p = SampleParams{dF, dls, nullptr, dty, dsc, dno, f_shared ? 0 : (long long)n * nF};
         io.p_shared_u = f_shared != 0;
         io.X = nullptr; io.nU = nF; io.nX = 0;
         io.Y = dtg; io.y_sstride = t_shared ? 0 : (long long)n;
-        io.L = 0; io.doT = ddo; io.logdet = old.as<double>(); io.quad = oq.as<double>(); io.info = info.as<int>();
+        io.L = 0; io.doT = ddo; io.logdet = old; io.quad = oq; io.info = c->io.take<int>((size_t)S);
         run_predict(c, io);
-        std::vector<double> ld(S), q(S);
-        HC(hipMemcpy(ld.data(), old.p, sizeof(double) * S, hipMemcpyDeviceToHost));
-        HC(hipMemcpy(q.data(), oq.p, sizeof(double) * S, hipMemcpyDeviceToHost));
-        const double l2pi = 1.8378770664093454835606594728112;
-        for (int64_t s = 0; s < S; ++s) logpdf[s] = -0.5 * ((double)c->n * l2pi + ld[s] + q[s]);
+        finish_logpdf(c, S, old, oq, logpdf);
         return first_info(c);
     });
 }
@@ -994,11 +1103,11 @@ int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* c
         }
         // z_s = L^-1 x_s for all S vectors: rows of W = X^T L^-T, tile-level left-looking solve
         const int naug = (int)((S + GP_TS - 1) / GP_TS);
-        DevBuf bx, wt, oq;
-        const double* dx = up(bx, x, (size_t)n * S);
-        wt.alloc((size_t)naug * nt * GP_TSQ * 8);
-        oq.alloc(sizeof(double) * S);
-        TRef W = rect_ref(wt.as<double>(), (long long)naug * nt * GP_TSQ, nt);
+        c->io.reset();
+        const double* dx = up(c, x, (size_t)n * S);
+        double* wt = c->io.take<double>((size_t)naug * nt * GP_TSQ);
+        double* oq = c->io.take<double>((size_t)S);
+        TRef W = rect_ref(wt, (long long)naug * nt * GP_TSQ, nt);
         TRef Ls = lower_ref(c->mvn_tiles, nlow * GP_TSQ);
         TRef invref = TRef{c->mvn_inv, (long long)nt * GP_TSQ, 1, 0, 0, 0};
         launch_rows_rhs(RowsRhsArgs{dx, S, n, nt, naug, W, 0, 1}, st);
@@ -1020,12 +1129,12 @@ int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* c
                 gemm(c, u, st);
             }
         }
-        launch_row_norms(RowNormArgs{W, nt, naug, S, oq.as<double>()}, st);
+        launch_row_norms(RowNormArgs{W, nt, naug, S, oq}, st);
         HC(hipStreamSynchronize(st));
         HC(hipGetLastError());
         if (c->flags & GPSLC_FLAG_PROFILE) prof_collect(c);
         std::vector<double> q(S);
-        HC(hipMemcpy(q.data(), oq.p, sizeof(double) * S, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(q.data(), oq, sizeof(double) * S, hipMemcpyDeviceToHost));
         const double l2pi = 1.8378770664093454835606594728112;
         for (int64_t s = 0; s < S; ++s) {
             const double sc = covscale ? covscale[s] : 1.0;

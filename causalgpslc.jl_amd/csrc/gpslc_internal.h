@@ -14,6 +14,51 @@
 #define GP_TS 128
 #define GP_TSQ (GP_TS * GP_TS)
 
+// ---------------------------------------------------------------------------------------
+// Per-device launch state.  hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only
+// and one process may hold a ctx per GPU, each driven by its own thread: every kernel
+// instantiation remembers, per device, whether the opt-in was applied.  Lock-free; two threads racing on the
+// same device both apply the (idempotent) attribute.
+// ---------------------------------------------------------------------------------------
+#include <atomic>
+#include <cstdlib>
+struct DeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+};
+inline void lds_opt_in(DeviceOnce& o, const void* fn, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (o.mask.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    o.mask.fetch_or(bit, std::memory_order_release);
+}
+// compute units of the current device (cached per device)
+inline int device_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int v = cus[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+        v = 256;
+        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        cus[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+// Measurement switches (tile visiting order, grid sizes, timing-only kernels, in-kernel stamps) exist only in the
+// -DGPSLC_DIAG build that tools/ and the profiling scripts use (libgpslc_hip_diag.so).  In the production library
+// the environment cannot change a result or a schedule: every switch reads as its default.
+inline int diag_env(const char* name, int dflt) {
+#ifdef GPSLC_DIAG
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 struct TRef {
     double* base;        // first tile of batch element 0
     long long bstride;   // doubles between consecutive batch elements

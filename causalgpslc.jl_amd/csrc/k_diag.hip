@@ -334,20 +334,12 @@ __global__ __launch_bounds__(256, 2) void diag_potrf_inv_v2_kernel(TRef M, int k
 
 void launch_diag(const TRef& M, int k, double* inv, long long inv_bstride, int* info,
                  int info_base, int nbatch, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)diag_potrf_inv_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES);
-        attr_set = true;
-    }
-    static const int v1 = [] { const char* e = getenv("GPSLC_DIAG_V1"); return (e && atoi(e) == 1) ? 1 : 0; }();
+    static DeviceOnce attr_set;
+    lds_opt_in(attr_set, (const void*)diag_potrf_inv_kernel, DIAG_LDS_BYTES);
+    static const int v1 = diag_env("GPSLC_DIAG_V1", 0) == 1 ? 1 : 0;
     if (!v1) {
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)diag_potrf_inv_v2_kernel,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, DIAG2_LDS_BYTES);
-            attr2 = true;
-        }
+        static DeviceOnce attr2;
+    lds_opt_in(attr2, (const void*)diag_potrf_inv_v2_kernel, DIAG2_LDS_BYTES);
         hipLaunchKernelGGL(diag_potrf_inv_v2_kernel, dim3(nbatch), dim3(256), DIAG2_LDS_BYTES, st, M, k, inv,
                            inv_bstride, info, info_base);
         return;

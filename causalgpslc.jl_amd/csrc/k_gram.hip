@@ -179,12 +179,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
 template <typename RT, int BIN, int FT>
 static void launch_gram_t(const GramArgs& g, int nbatch, hipStream_t st) {
     const int F = g.nU + g.nX;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gram_kernel<RT, BIN, FT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  GRAM_LDS_BYTES(MAXF, (int)sizeof(RT)));
-        attr_set = true;
-    }
+    static DeviceOnce attr_set;
+    lds_opt_in(attr_set, (const void*)gram_kernel<RT, BIN, FT>, GRAM_LDS_BYTES(MAXF, (int)sizeof(RT)));
     // one workgroup per (tile, sample): a persistent variant measured 0.7 % slower (same-box A/B)
     const int nlow = g.nt * (g.nt + 1) / 2;
     hipLaunchKernelGGL((gram_kernel<RT, BIN, FT>), dim3(nlow, nbatch), dim3(256), GRAM_LDS_BYTES(F, (int)sizeof(RT)), st, g);

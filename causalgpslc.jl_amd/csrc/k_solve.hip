@@ -370,13 +370,8 @@ static void launch_ite_mean_mfma_tb(const IteMeanArgs& a, int nbatch, hipStream_
     const int F = a.nU + a.nX;
     const int FS = FREG > F ? FREG : F;
     const int bytes = (F * GP_TS + FS * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ite_mean_mfma_kernel<FREG, BIN>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (MAXF * GP_TS + MAXF * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8);
-        attr_set = true;
-    }
+    static DeviceOnce attr_set;
+    lds_opt_in(attr_set, (const void*)ite_mean_mfma_kernel<FREG, BIN>, (MAXF * GP_TS + MAXF * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8);
     hipLaunchKernelGGL((ite_mean_mfma_kernel<FREG, BIN>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
 }
 template <int FREG>
@@ -398,12 +393,8 @@ template <int FREG, int LCT, typename RT, int BIN>
 static void launch_ite_mean_tb(const IteMeanArgs& a, int nbatch, hipStream_t st) {
     constexpr int RB = 1;     // row blocks per workgroup (2 measured slower: occupancy)
     const int bytes = (GP_TS + (1 + RB) * LCT * GP_TS) * 8 + (FREG * GP_TS + GP_TS) * (int)sizeof(RT);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ite_mean_kernel<FREG, LCT, RT, RB, BIN>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        attr_set = true;
-    }
+    static DeviceOnce attr_set;
+    lds_opt_in(attr_set, (const void*)ite_mean_kernel<FREG, LCT, RT, RB, BIN>, bytes);
     hipLaunchKernelGGL((ite_mean_kernel<FREG, LCT, RT, RB, BIN>), dim3((a.nt + RB - 1) / RB, nbatch), dim3(256), bytes, st, a);
 }
 template <int FREG, int LCT, typename RT>
@@ -518,12 +509,8 @@ __global__ __launch_bounds__(256) void dt_build_kernel(DtArgs a) {
 #define DT_LDS_BYTES(F) ((2 * (F) * GP_TS + 4 * GP_TS) * 8)
 
 void launch_dt_build(const DtArgs& a, int nbatch, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dt_build_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS_BYTES(MAXF));
-        attr_set = true;
-    }
+    static DeviceOnce attr_set;
+    lds_opt_in(attr_set, (const void*)dt_build_kernel, DT_LDS_BYTES(MAXF));
     hipLaunchKernelGGL(dt_build_kernel, dim3(a.nt * a.nt, nbatch), dim3(256), DT_LDS_BYTES(a.nU + a.nX), st, a);
 }
 
@@ -706,12 +693,8 @@ __global__ __launch_bounds__(256) void ld_build_kernel(LdBuildArgs a) {
 void launch_ld_build(const LdBuildArgs& a, hipStream_t st) {
     const int F = a.nU + a.nX;
     const int bytes = (2 * F * GP_TS + 4 * GP_TS) * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ld_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (2 * MAXF * GP_TS + 4 * GP_TS) * 8);
-        attr_set = true;
-    }
+    static DeviceOnce attr_set;
+    lds_opt_in(attr_set, (const void*)ld_build_kernel, (2 * MAXF * GP_TS + 4 * GP_TS) * 8);
     hipLaunchKernelGGL(ld_build_kernel, dim3(a.nt * a.nt), dim3(256), bytes, st, a);
 }
 
@@ -781,11 +764,7 @@ __global__ __launch_bounds__(256) void summarize_kernel(SummArgs a) {
     }
 }
 void launch_summarize(const SummArgs& a, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)summarize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  16384 * 8);
-        attr_set = true;
-    }
+    static DeviceOnce attr_set;
+    lds_opt_in(attr_set, (const void*)summarize_kernel, 16384 * 8);
     hipLaunchKernelGGL(summarize_kernel, dim3(a.n), dim3(256), (size_t)a.mpad * 8, st, a);
 }

@@ -29,10 +29,18 @@
 //   * XCD-aware work split: XCD x (blockIdx % 8) owns the x-th contiguous run of work items, so the
 //     workgroups that share an L2 work on neighbouring tiles of the same matrices.
 #include "gpslc_internal.h"
-#include <cstdlib>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+
+// measurement-only paths (in-kernel stamps, timing-only variants) exist in the -DGPSLC_DIAG build only
+#ifdef GPSLC_DIAG
+#define GP_DBG_ON(g) ((g).dbg != nullptr)
+#define GP_DIAG_SKIP(g) ((g).diag_skip)
+#else
+#define GP_DBG_ON(g) false
+#define GP_DIAG_SKIP(g) 0
+#endif
 
 #define KS 16
 #define LROW 144                      // padded k-row (doubles)
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
             if (!FUSE) break;
             no_update = true;
         }
-        if (g.diag_skip == 3 && g.short_rows > 0 && ti >= g.short_row0) break;   // timing-only: price of the short tiles
+        if (GP_DIAG_SKIP(g) == 3 && g.short_rows > 0 && ti >= g.short_row0) break;   // timing-only: price of the short tiles
 
         double* __restrict__ Ct = tref_tile(g.C, b, ti, tj);
         // augmented right-hand-side rows hold only `short_rows` live rows: this wave's number of live
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         int prow = 8;                                     // live 16-row blocks of this tile
         if (!ACC && g.short_rows > 0 && ti >= g.short_row0) prow = min(8, (g.short_rows + 15) >> 4);
         unsigned long long st0 = 0, st1 = 0, st2 = 0;
-        if (g.dbg) st0 = __builtin_amdgcn_s_memtime();
+        if (GP_DBG_ON(g)) st0 = __builtin_amdgcn_s_memtime();
 
         // ---- accumulators: acc[m][n][v] = C[wr*64 + 16m + (lane&15)][wc*64 + 16n + (lane>>4) + 4v]
         d4 acc[4][4];
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
             lstore(0, ra, rb);
             gload(1, ra, rb);          // nslab is a multiple of 8
             __syncthreads();
-            if (g.dbg) st1 = __builtin_amdgcn_s_memtime();
+            if (GP_DBG_ON(g)) st1 = __builtin_amdgcn_s_memtime();
             // unrolled by two, the staging sets swapping roles: set A holds slab s+1 while slab s+2
             // streams into set B.  The barrier that ends the last slab also protects the LDS buffers
             // against the next work item's first lstore.
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                 }
             }
         }
-        if (g.dbg) st2 = __builtin_amdgcn_s_memtime();
+        if (GP_DBG_ON(g)) st2 = __builtin_amdgcn_s_memtime();
 
         if (FUSE) {
             const int li = lane & 15, lg = lane >> 4;
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                     Cs[(16 * n + 4 * v) * GP_TS + 16 * m] = acc[m][n][v];
         }
         }
-        if (g.dbg) {   // diagnostic stamps: go to a buffer nothing else reads
+        if (GP_DBG_ON(g)) {   // diagnostic stamps: go to a buffer nothing else reads
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long st3 = __builtin_amdgcn_s_memtime();
             if (tid == 0) {
@@ -559,12 +567,8 @@ __global__ __launch_bounds__(256, 2) void tile_syrk_diag_kernel(GemmArgs g) {
 
 template <int MT>
 static void launch_syrk_diag_t(const GemmArgs& g, unsigned grid, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tile_syrk_diag_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  DG_LDS_BYTES(MT));
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    lds_opt_in(once, (const void*)tile_syrk_diag_kernel<MT>, DG_LDS_BYTES(MT));
     hipLaunchKernelGGL(tile_syrk_diag_kernel<MT>, dim3(grid), dim3(256), DG_LDS_BYTES(MT), st, g);
 }
 
@@ -572,13 +576,7 @@ static void launch_syrk_diag_t(const GemmArgs& g, unsigned grid, hipStream_t st)
 // carry_aug: the items also update the augmented-row tiles (short_row0, i0 + t) (live rows g.short_rows).
 void launch_syrk_diag(const GemmArgs& g, int carry_aug, hipStream_t st) {
     if (g.mi <= 0 || g.nbatch <= 0 || g.k1 <= g.k0) return;
-    static int slots = 0;
-    if (slots == 0) {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        slots = 2 * cus;
-    }
+    const int slots = 2 * device_cus();
     const long long Wk = (long long)g.mi * g.nbatch;
     const unsigned grid = (unsigned)(Wk < slots ? Wk : slots);
     const int mt = carry_aug ? (g.short_rows + 15) / 16 : 0;   // callers pass carry_aug only for mt <= 2
@@ -589,34 +587,32 @@ void launch_syrk_diag(const GemmArgs& g, int carry_aug, hipStream_t st) {
 
 template <int ACC, int DIAG, int FUSE = 0>
 static void launch_one(const GemmArgs& g, unsigned grid, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tile_gemm_nt_kernel<ACC, DIAG, FUSE>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        attr_set = true;
-    }
+    static DeviceOnce once;
+    lds_opt_in(once, (const void*)tile_gemm_nt_kernel<ACC, DIAG, FUSE>, GEMM_LDS_BYTES);
     hipLaunchKernelGGL((tile_gemm_nt_kernel<ACC, DIAG, FUSE>), dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
 }
 
 void launch_tile_gemm(const GemmArgs& g, hipStream_t st) {
     if (g.ntiles <= 0 || g.nbatch <= 0) return;
-    static int slots = 0;
-    if (slots == 0) {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        slots = 2 * cus;   // 2 workgroups per CU (227 VGPRs, 72 KiB LDS each)
-        if (const char* e = getenv("GPSLC_GEMM_SLOTS")) slots = atoi(e);   // experiments only
-    }
+    int slots = 2 * device_cus();   // 2 workgroups per CU (227 VGPRs, 72 KiB LDS each)
     const long long W = (long long)g.ntiles * g.nbatch;
-    static const int panel_slots = [] { const char* e = getenv("GPSLC_PANEL_SLOTS"); return e ? atoi(e) : 0; }();
-    const int use_slots = (!g.accumulate && panel_slots > 0) ? panel_slots : slots;   // experiments only
-    const unsigned grid = (unsigned)(W < use_slots ? W : use_slots);
+#ifdef GPSLC_DIAG
+    slots = diag_env("GPSLC_GEMM_SLOTS", slots);
+    const int panel_slots = diag_env("GPSLC_PANEL_SLOTS", 0);
+    if (!g.accumulate && panel_slots > 0) slots = panel_slots;
+#endif
+    const unsigned grid = (unsigned)(W < slots ? W : slots);
+#ifdef GPSLC_DIAG
     if (g.diag_skip == 1) {        // timing-only diagnostics (GPSLC_GEMM_DIAG), separate instantiations
         if (g.accumulate) launch_one<1, 1>(g, grid, st); else launch_one<0, 1>(g, grid, st);
-    } else if (g.diag_skip == 2) {
+        return;
+    }
+    if (g.diag_skip == 2) {
         if (g.accumulate) launch_one<1, 2>(g, grid, st); else launch_one<0, 2>(g, grid, st);
-    } else if (g.fuse && g.accumulate) {
+        return;
+    }
+#endif
+    if (g.fuse && g.accumulate) {
         launch_one<1, 0, 1>(g, grid, st);
     } else {
         if (g.accumulate) launch_one<1, 0>(g, grid, st); else launch_one<0, 0>(g, grid, st);

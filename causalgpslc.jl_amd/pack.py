@@ -4,6 +4,10 @@ prediction path: everything `extractParameters` (src/utils.jl:92-124) yields for
 i in nBurnIn:stepSize:nOuter, stacked, in Julia's own column-major order — so the Julia-side writer is a
 handful of `write(io, ...)` calls and the reader needs no Julia.
 
+The reader and writer are the C functions of the library (gpslc_pack_save / gpslc_pack_read_header /
+gpslc_pack_load, include/gpslc_hip.h) so that any host language binds the same code; this module only
+allocates the NumPy buffers.
+
 Layout (all little-endian):
     8 bytes   magic  b"GPSLCPK1"
     6 x int64 n, nX, nU, S, binaryT (0/1), reserved (0)
@@ -13,54 +17,77 @@ Layout (all little-endian):
 """
 from __future__ import annotations
 
-import struct
+import ctypes as C
+import os
+from typing import Optional, Tuple
 
 import numpy as np
 
-from .api import GPSLCObject, HyperParameters
+from . import _lib
+from .api import GPSLCObject, HyperParameters, _p
 
 MAGIC = b"GPSLCPK1"
 
 
+def _raise(st, what):
+    if st == -1005:
+        raise OSError(f"{what}: file cannot be opened, read or written")
+    if st == -1006:
+        raise ValueError(f"{what}: not a GPSLC posterior pack (bad magic, truncated or trailing bytes)")
+    raise _lib.GPSLCError(st, what)
+
+
 def saveGPSLCObject(g: GPSLCObject, path: str, binary_t: bool = False) -> None:
     """saveGPSLCObject(g, filename) (src/io.jl:14-19) in the flat pack format."""
-    n, nX, nU, S = g.getN(), g.getNX(), g.getNU(), g.getNumPosteriorSamples()
+    lib = _lib.load()
     hp = g.hyperparams
-    with open(path, "wb") as f:
-        f.write(MAGIC)
-        f.write(struct.pack("<6q", n, nX, nU, S, 1 if binary_t else 0, 0))
-        f.write(struct.pack("<7d", -1.0 if hp.nU is None else float(hp.nU), hp.nOuter, hp.nMHInner, hp.nESInner,
-                            hp.nBurnIn, hp.stepSize, hp.predictionCovarianceNoise))
-        for a in (g.X, g.T, g.Y, g.U, g.uyLS, g.xyLS, g.tyLS, g.yNoise, g.yScale):
-            if a is not None:
-                f.write(np.asfortranarray(a, dtype="<f8").tobytes(order="F"))
+    h = _lib.PackHeader(g.getN(), g.getNX(), g.getNU(), g.getNumPosteriorSamples(), 1 if binary_t else 0, 0)
+    for i, v in enumerate((-1.0 if hp.nU is None else float(hp.nU), hp.nOuter, hp.nMHInner, hp.nESInner, hp.nBurnIn,
+                           hp.stepSize, hp.predictionCovarianceNoise)):
+        h.hyper[i] = float(v)
+    arrs = [None if a is None else np.asfortranarray(a, dtype=np.float64)
+            for a in (g.X, g.T, g.Y, g.U, g.uyLS, g.xyLS, g.tyLS, g.yNoise, g.yScale)]
+    st = lib.gpslc_pack_save(os.fsencode(path), C.byref(h), *[_p(a) for a in arrs])
+    if st != 0:
+        _raise(st, f"gpslc_pack_save({path})")
 
 
-def loadGPSLCObject(path: str, device: int = 0) -> GPSLCObject:
-    """loadGPSLCObject(filename) (src/io.jl:29-34) from the flat pack format."""
-    with open(path, "rb") as f:
-        if f.read(8) != MAGIC:
-            raise ValueError("not a GPSLC posterior pack")
-        n, nX, nU, S, binary_t, _ = struct.unpack("<6q", f.read(48))
-        hpv = struct.unpack("<7d", f.read(56))
+def readPackHeader(path: str) -> dict:
+    """Sizes and hyper-parameters of a pack without reading its arrays."""
+    lib = _lib.load()
+    h = _lib.PackHeader()
+    st = lib.gpslc_pack_read_header(os.fsencode(path), C.byref(h))
+    if st != 0:
+        _raise(st, f"gpslc_pack_read_header({path})")
+    return {"n": h.n, "nX": h.nX, "nU": h.nU, "S": h.S, "binary_t": bool(h.binary_t), "hyper": list(h.hyper)}
 
-        def rd(*shape):
-            cnt = int(np.prod(shape))
-            if cnt == 0:
-                return None
-            buf = f.read(8 * cnt)
-            if len(buf) != 8 * cnt:
-                raise ValueError("truncated posterior pack")
-            return np.frombuffer(buf, dtype="<f8").reshape(shape, order="F").copy(order="F")
 
-        X = rd(n, nX)
-        T, Y = rd(n), rd(n)
-        U, uyLS, xyLS = rd(n, nU, S), rd(nU, S), rd(nX, S)
-        tyLS, yNoise, yScale = rd(S), rd(S), rd(S)
-        if f.read(1):
-            raise ValueError("trailing bytes in posterior pack")
+def loadGPSLCObject(path: str, device: int = 0, samples: Optional[Tuple[int, int]] = None,
+                    fp32_kernel: bool = False) -> GPSLCObject:
+    """loadGPSLCObject(filename) (src/io.jl:29-34) from the flat pack format.  ``samples = (s0, s1)`` loads only
+    that contiguous block of posterior samples — what one rank of a sharded prediction needs."""
+    lib = _lib.load()
+    hd = readPackHeader(path)
+    n, nX, nU, S = hd["n"], hd["nX"], hd["nU"], hd["S"]
+    s0, s1 = (0, S) if samples is None else (int(samples[0]), int(samples[1]))
+    if not 0 <= s0 <= s1 <= S:
+        raise IndexError(f"sample block [{s0}, {s1}) outside 0..{S}")
+    Sl = s1 - s0
+
+    def buf(*shape, samples=False):
+        lead = shape[:-1] if samples else shape      # an empty sample block keeps its (zero-length) arrays
+        return np.empty(shape, order="F") if all(d > 0 for d in lead) else None
+
+    X, T, Y = buf(n, nX), buf(n), buf(n)
+    U, uyLS, xyLS = buf(n, nU, Sl, samples=True), buf(nU, Sl, samples=True), buf(nX, Sl, samples=True)
+    tyLS, yNoise, yScale = buf(Sl, samples=True), buf(Sl, samples=True), buf(Sl, samples=True)
+    st = lib.gpslc_pack_load(os.fsencode(path), s0, s1, *[_p(a) for a in (X, T, Y, U, uyLS, xyLS, tyLS, yNoise, yScale)])
+    if st != 0:
+        _raise(st, f"gpslc_pack_load({path})")
+    hpv = hd["hyper"]
     hp = HyperParameters(None if hpv[0] < 0 else int(hpv[0]), int(hpv[1]), int(hpv[2]), int(hpv[3]), int(hpv[4]),
                          int(hpv[5]), hpv[6])
-    g = GPSLCObject(X, T, Y, U, uyLS, xyLS, tyLS, yNoise, yScale, hyperparams=hp, device=device)
-    g.binary_t = bool(binary_t)
+    g = GPSLCObject(X, T, Y, U, uyLS, xyLS, tyLS, yNoise, yScale, hyperparams=hp, device=device,
+                    fp32_kernel=fp32_kernel)
+    g.binary_t = hd["binary_t"]
     return g

@@ -20,6 +20,12 @@
  *   - calls on one ctx must be serialised by the caller; use one ctx per GPU / per thread.
  *   - "_dev" variants take DEVICE pointers (hipMalloc'ed / torch / AMDGPU.jl memory on the
  *     ctx's device) for every array argument; the plain variants take HOST pointers.
+ *   - stream contract of the "_dev" variants: the library works on private non-blocking HIP streams of
+ *     the ctx.  The caller must have completed (synchronised) whatever produced its device inputs
+ *     before the call; when the call returns every output is complete and visible to any stream.
+ *   - thread safety: distinct ctxs may be used concurrently from distinct threads (also on the same
+ *     GPU); the library keeps no process-global mutable state besides per-device "attribute applied"
+ *     bits, which are atomic.  The environment is never consulted by this library.
  */
 #ifndef GPSLC_HIP_H
 #define GPSLC_HIP_H
@@ -38,6 +44,8 @@ typedef struct gpslc_ctx gpslc_ctx;
 #define GPSLC_ERR_NODATA     (-1002)  /* gpslc_set_data has not been called               */
 #define GPSLC_ERR_NODEVICE   (-1003)  /* no usable gfx950 device                          */
 #define GPSLC_ERR_INTERNAL   (-1004)
+#define GPSLC_ERR_IO         (-1005)  /* posterior pack: file cannot be opened / read / written   */
+#define GPSLC_ERR_FORMAT     (-1006)  /* posterior pack: bad magic, truncated or trailing bytes   */
 
 /* flags for gpslc_create */
 #define GPSLC_FLAG_DEFAULT            0u
@@ -69,11 +77,17 @@ const char* gpslc_last_error(const gpslc_ctx* ctx);
  * out[i + n*ip] = -sum_k (X1[i,k] - X2[ip,k])^2 / LS[k]^2, ls_len = 1 (scalar LS) or d. */
 int gpslc_rbf_log(gpslc_ctx* ctx, const double* X1, const double* X2, int64_t n, int32_t d,
                   const double* ls, int32_t ls_len, double* out);
+/* device pointers for X1, X2, ls and out: no allocation, no copy (src/inference.jl:225-227, 286-287, 343-344
+ * call rbfKernelLog / processCov once per outer MCMC iteration) */
+int gpslc_rbf_log_dev(gpslc_ctx* ctx, const double* X1, const double* X2, int64_t n, int32_t d,
+                      const double* ls, int32_t ls_len, double* out);
 
 /* processCov(logCov, scale[, noise]) (src/kernel.jl:53-55, 57-59): out = exp.(logcov)*scale
  * + noise*I.  The two-argument method is noise = 0.0. */
 int gpslc_process_cov(gpslc_ctx* ctx, const double* logcov, int64_t n, double scale, double noise,
                       double* out);
+int gpslc_process_cov_dev(gpslc_ctx* ctx, const double* logcov, int64_t n, double scale, double noise,
+                          double* out);   /* device pointers; out may alias logcov */
 
 /* ---- src/model_likelihood.jl :Y node -------------------------------------------------- */
 
@@ -81,10 +95,12 @@ int gpslc_process_cov(gpslc_ctx* ctx, const double* logcov, int64_t n, double sc
  * tyCovLog, yScale, yNoise): generateYfromUXT / UT / XT / T (src/model_likelihood.jl:83-91,
  * 94-101, 104-111, 114-120).  U: n x nU (ignored when nU == 0).  X_or_null: overrides the ctx's
  * X for this call (the trace's :X => k => :X values; n x nX) or NULL to use gpslc_set_data's.
- * Uses the ctx's T and Y.  S independent parameter sets are evaluated per call (S = 1 for one
- * Gen `update`); U is n x nU x S, uyLS nU x S, xyLS nX x S, the rest length S. */
+ * Y_or_null: the value being scored (n) — what Gen hands to a Distribution's logpdf — or NULL for
+ * the ctx's Y (the constrained observation, src/model_likelihood.jl:89).  Uses the ctx's T.
+ * S independent parameter sets are evaluated per call (S = 1 for one Gen `update`); U is
+ * n x nU x S, uyLS nU x S, xyLS nX x S, the rest length S. */
 int gpslc_y_logpdf(gpslc_ctx* ctx, int64_t S, const double* U, const double* X_or_null,
-                   const double* uyLS, const double* xyLS, const double* tyLS,
+                   const double* Y_or_null, const double* uyLS, const double* xyLS, const double* tyLS,
                    const double* yScale, const double* yNoise, double* logpdf /* S */);
 
 /* ---- the other Gaussian-process nodes of the Gen models -------------- */
@@ -176,6 +192,26 @@ int gpslc_summarize_dev(gpslc_ctx* ctx, const double* samples, int64_t n, int64_
 /* 1-based failing pivot (0 = ok) of every posterior sample of the last predict / y_logpdf /
  * ite_distributions call; codes > n refer to the CovITE factorisation (pivot - n). */
 int gpslc_last_info(const gpslc_ctx* ctx, int32_t* info, int64_t S);
+
+/* ---- posterior pack (replaces Serialization of a GPSLCObject, src/io.jl:14-34) ----
+ * Flat little-endian file: magic "GPSLCPK1"; 6 x int64 {n, nX, nU, S, binaryT, 0}; 7 x f64 hyper-parameters
+ * {nU or -1, nOuter, nMHInner, nESInner, nBurnIn, stepSize, predictionCovarianceNoise} (src/types.jl:22-30);
+ * then the f64 arrays X[n,nX] T[n] Y[n] U[n,nU,S] uyLS[nU,S] xyLS[nX,S] tyLS[S] yNoise[S] yScale[S], column-
+ * major — what extractParameters (src/utils.jl:92-124) yields for the retained samples, stacked.
+ * Host-only functions (no ctx, no GPU). */
+typedef struct gpslc_pack_header {
+    int64_t n, nX, nU, S, binary_t, reserved;
+    double hyper[7];
+} gpslc_pack_header;
+
+int gpslc_pack_save(const char* path, const gpslc_pack_header* h, const double* X, const double* T,
+                    const double* Y, const double* U, const double* uyLS, const double* xyLS,
+                    const double* tyLS, const double* yNoise, const double* yScale);
+int gpslc_pack_read_header(const char* path, gpslc_pack_header* h);
+/* Reads the data and the posterior samples [s0, s1) (0 <= s0 <= s1 <= S) into caller buffers sized for
+ * s1 - s0 samples — a rank of a sharded prediction loads only its own block.  Any output may be NULL (skipped). */
+int gpslc_pack_load(const char* path, int64_t s0, int64_t s1, double* X, double* T, double* Y, double* U,
+                    double* uyLS, double* xyLS, double* tyLS, double* yNoise, double* yScale);
 
 /* ---- measurement hooks (bench.py, profiles/) ----------------------------------------- */
 

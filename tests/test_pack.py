@@ -35,6 +35,39 @@ def test_rejects_garbage(tmp_path):
         gp.loadGPSLCObject(str(tmp_path / "t.pk"))
 
 
+def test_sample_block_loading_and_c_header(tmp_path):
+    """A rank of a sharded prediction loads only its own block of posterior samples (gpslc_pack_load s0, s1)."""
+    from causalgpslc_jl_amd.pack import readPackHeader
+    c = cases.make_case(23, "UX", True, S=7, seed=5)
+    g = cases.gpslc_object(gp, c)
+    p = str(tmp_path / "g.pk")
+    gp.saveGPSLCObject(g, p, binary_t=True)
+    hd = readPackHeader(p)
+    assert (hd["n"], hd["nX"], hd["nU"], hd["S"], hd["binary_t"]) == (23, 3, 2, 7, True)
+    # the Python writer of round 1 and the C writer produce the same bytes (format is frozen)
+    import struct
+    hp = g.hyperparams
+    raw = b"GPSLCPK1" + struct.pack("<6q", 23, 3, 2, 7, 1, 0) + struct.pack(
+        "<7d", float(hp.nU), hp.nOuter, hp.nMHInner, hp.nESInner, hp.nBurnIn, hp.stepSize, hp.predictionCovarianceNoise)
+    for a in (g.X, g.T, g.Y, g.U, g.uyLS, g.xyLS, g.tyLS, g.yNoise, g.yScale):
+        raw += np.asfortranarray(a, dtype="<f8").tobytes(order="F")
+    assert open(p, "rb").read() == raw
+    for s0, s1 in ((0, 7), (2, 5), (6, 7), (3, 3)):
+        h = gp.loadGPSLCObject(p, samples=(s0, s1))
+        assert gp.getNumPosteriorSamples(h) == s1 - s0
+        assert np.array_equal(h.X, g.X) and np.array_equal(h.Y, g.Y)
+        if s1 > s0:
+            assert np.array_equal(h.U, g.U[:, :, s0:s1]) and np.array_equal(h.xyLS, g.xyLS[:, s0:s1])
+            assert np.array_equal(h.tyLS, g.tyLS[s0:s1]) and np.array_equal(h.yScale, g.yScale[s0:s1])
+    with pytest.raises(IndexError):
+        gp.loadGPSLCObject(p, samples=(5, 9))
+    with pytest.raises(OSError):
+        gp.loadGPSLCObject(str(tmp_path / "missing.pk"))
+    (tmp_path / "long.pk").write_bytes(raw + b"\0" * 8)     # trailing bytes
+    with pytest.raises(ValueError):
+        gp.loadGPSLCObject(str(tmp_path / "long.pk"))
+
+
 @pytest.mark.gpu
 def test_prediction_from_reloaded_pack_is_identical(tmp_path):
     c = cases.make_case(140, "UX", False, S=3, seed=9)
