@@ -12,9 +12,9 @@ from .api import (  # noqa: F401
     summarizeEstimates, yLogpdf, gpLogpdf, mvnLogpdf, predict, doTRange, getN, getNX, getNU, getNumPosteriorSamples,
 )
 from . import synth  # noqa: F401
-from .pack import saveGPSLCObject, loadGPSLCObject  # noqa: F401
+from .pack import saveGPSLCObject, loadGPSLCObject, readPackHeader  # noqa: F401
 from .inference import (  # noqa: F401
     gpslc, Posterior, prepareData, generateSigmaU, removeAdjacent, getPriorParameters, getHyperParameters,
     toMatrixModel,
 )
-from .sharded import predict_sharded, shard_range  # noqa: F401
+from .sharded import predict_sharded, predict_sharded_pack, shard_range  # noqa: F401

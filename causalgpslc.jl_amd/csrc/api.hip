@@ -95,8 +95,9 @@ struct DevBuf {   // RAII device allocation for the host-pointer entry points
 struct ProfRec {
     hipEvent_t a, b;
     double flop;
-    int cls;     // 0: tile_gemm_nt_kernel<1, 0, 0> (trailing updates, SYRKs), 1: <1, 0, 1> (fused in-panel launches)
+    int cls;     // kernel class, see gpslc_profile_get_class (include/gpslc_hip.h)
 };
+constexpr int kProfClasses = 4;
 
 }  // namespace
 
@@ -130,8 +131,8 @@ struct gpslc_ctx {
     // profiling of the dominant kernel
     std::vector<ProfRec> prof;
     size_t prof_used = 0;
-    int64_t prof_launches[2] = {0, 0};     // per kernel class, see ProfRec::cls
-    double prof_ms[2] = {0.0, 0.0}, prof_flop[2] = {0.0, 0.0};
+    int64_t prof_launches[kProfClasses] = {};     // per kernel class, see ProfRec::cls
+    double prof_ms[kProfClasses] = {}, prof_flop[kProfClasses] = {};
 };
 
 namespace {
@@ -139,6 +140,26 @@ namespace {
 void set_err(gpslc_ctx* c, const std::string& s) {
     if (c) c->err = s;
 }
+
+// HIP events around a launch region on `st` (GPSLC_FLAG_PROFILE only): accumulates into kernel class `cls`
+struct ProfScope {
+    gpslc_ctx* c;
+    ProfRec* r = nullptr;
+    hipStream_t st;
+    ProfScope(gpslc_ctx* c_, int cls, double work, hipStream_t st_) : c(c_), st(st_) {
+        if (!(c->flags & GPSLC_FLAG_PROFILE)) return;
+        if (c->prof_used == c->prof.size()) {
+            ProfRec n{};
+            if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
+            c->prof.push_back(n);
+        }
+        r = &c->prof[c->prof_used++];
+        r->flop = work;
+        r->cls = cls;
+        (void)hipEventRecord(r->a, st);
+    }
+    ~ProfScope() { if (r) (void)hipEventRecord(r->b, st); }
+};
 
 int fail_hip(gpslc_ctx* c, const HipFail& f) {
     char buf[512];
@@ -217,7 +238,7 @@ static void launch_sym_diag_tiles(const GemmArgs& g, hipStream_t st) {
     launch_syrk_diag(d, g.sym == 3 && g.short_rows > 0, st);
 }
 
-void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
+void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st, int prof_base = 0) {
     GemmArgs g = g0;
     g.diag_skip = 0;
     g.dbg = nullptr;
@@ -256,14 +277,6 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
     };
     const bool prof = (c->flags & GPSLC_FLAG_PROFILE) && g.accumulate;
     if (prof) {
-        if (c->prof_used == c->prof.size()) {
-            ProfRec r;
-            HC(hipEventCreate(&r.a));
-            HC(hipEventCreate(&r.b));
-            r.flop = 0;
-            c->prof.push_back(r);
-        }
-        ProfRec& r = c->prof[c->prof_used++];
         // algorithmic flop: full tiles count 2*128^3 per K tile, items in the (single) augmented row only
         // their live right-hand-side rows
         double short_items = 0;
@@ -285,14 +298,14 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st) {
         if (g.sym == 3 && short_items > 0) short_exec = (g.shape == 0) ? 1.0 : 0.0;
         const double rows = GP_TS * ((double)g.ntiles - short_items - diag_out * diag_items)
                           + (double)g.short_rows * short_exec;
-        r.flop = 2.0 * GP_TS * GP_TS * rows * (double)(g.k1 - g.k0) * (double)g.nbatch;
+        double flop = 2.0 * GP_TS * GP_TS * rows * (double)(g.k1 - g.k0) * (double)g.nbatch;
         // fused panel product: one triangular solve per tile row = 128^2 * 128 multiply-adds... counted as the
         // textbook n^2 b flop of a TRSM (the kernel runs 56 % of the dense 2*128^3 product)
-        if (g.fuse) r.flop += (double)GP_TS * GP_TS * rows * (double)g.nbatch;
-        r.cls = g.fuse ? 1 : 0;
-        HC(hipEventRecord(r.a, st));
-        launch_tile_gemm(g, st);
-        HC(hipEventRecord(r.b, st));
+        if (g.fuse) flop += (double)GP_TS * GP_TS * rows * (double)g.nbatch;
+        {
+            ProfScope ps(c, prof_base ? prof_base : (g.fuse ? 1 : 0), flop, st);
+            launch_tile_gemm(g, st);
+        }
         launch_diag_tiles();
     } else {
         launch_tile_gemm(g, st);
@@ -357,7 +370,7 @@ TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstri
 // trailing (ntot-nt)^2 block its Schur complement.  Panels of `pw` tile columns: left-looking inside a
 // panel, one right-looking trailing update (K = pw*128) per panel.
 void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, long long inv_bstride,
-                 int* info, int info_base, int nb, hipStream_t st, int aug_rows = 0) {
+                 int* info, int info_base, int nb, hipStream_t st, int aug_rows = 0, int prof_base = 0) {
     // aug_rows > 0: the tile rows nt.. hold only that many live rows in total (right-hand sides);
     // a single augmented tile row is the common case and the only one the kernel shortens
     const int short_rows = (aug_rows > 0 && ntot == nt + 1) ? aug_rows : 0;
@@ -383,10 +396,10 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
                 launch_sym_diag_tiles(g, st);
                 launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
                 g.fuse = 1; g.F = invref; g.fk = k;
-                gemm(c, g, st);
+                gemm(c, g, st, prof_base);
                 fused = true;
             } else {
-                gemm(c, g, st);
+                gemm(c, g, st, prof_base);
             }
         }
         if (!fused) launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
@@ -396,7 +409,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             g.shape = 1; g.i0 = k + 1; g.j0 = k; g.mi = ntot - k - 1; g.mj = 1;
             g.k0 = k; g.k1 = k + 1; g.accumulate = 0; g.nbatch = nb; g.ntiles = g.mi;
             g.short_row0 = nt; g.short_rows = short_rows;
-            gemm(c, g, st);
+            gemm(c, g, st, prof_base);
         }
         if (k == kend - 1 && ntot - kend > 0) {   // trailing update with the whole panel
             GemmArgs g{};
@@ -406,7 +419,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             g.k0 = ka; g.k1 = kend; g.accumulate = 1; g.nbatch = nb; g.ntiles = m * (m + 1) / 2;
             g.order = tri_order(c, m);
             g.short_row0 = nt; g.short_rows = short_rows;
-            gemm(c, g, st);
+            gemm(c, g, st, prof_base);
         }
     }
 }
@@ -569,13 +582,17 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
             double* Wt = ar.take<double>((size_t)Bb * nt * nt * GP_TSQ);
             double* Ct = ar.take<double>((size_t)Bb * nlow * GP_TSQ);
             double* inv2 = ar.take<double>((size_t)Bb * nt * GP_TSQ);
+            // draws: the library's own normals of one level of the sub-batch (generated once per unit), and for a
+            // level sweep the staging buffer [b][l][d][i] that is rearranged into the level-fastest tensor at the end
+            double* zgen = (want_draws && !io.z) ? ar.take<double>((size_t)Bb * io.spp * n) : nullptr;
+            double* dtmp = (want_draws && L > 1) ? ar.take<double>((size_t)Bb * L * io.spp * n) : nullptr;
             const long long wbs = (long long)nt * nt * GP_TSQ, cbs = nlow * GP_TSQ;
             std::vector<double> hdoT(L);
             HC(hipMemcpyAsync(hdoT.data(), io.doT, sizeof(double) * L, hipMemcpyDeviceToHost, st));
             HC(hipStreamSynchronize(st));
-            for (int l = 0; l < L; ++l) {
-                for (int u0 = 0; u0 < nb; u0 += Bb) {
-                    const int ub = std::min(Bb, nb - u0);
+            for (int u0 = 0; u0 < nb; u0 += Bb) {
+                const int ub = std::min(Bb, nb - u0);
+                for (int l = 0; l < L; ++l) {
                     TRef W = rect_ref(Wt, wbs, nt);
                     TRef Cm = lower_ref(Ct, cbs);
                     TRef Ls = lower_ref(tiles + (long long)u0 * bstride, bstride);
@@ -584,21 +601,26 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                     da.n = n; da.nX = io.nX; da.nU = io.nU; da.nt = nt; da.doT = hdoT[l];
                     da.pred_noise = io.pred_noise; da.W = W; da.Cm = Cm;
                     launch_dt_build(da, ub, st);
-                    // W <- D L^-T (left-looking over tile columns)
+                    // W <- D L^-T, left-looking over tile columns; the panel product with inv(L_kk)^T is applied by the
+                    // same work item that finishes the column update (the tile makes one HBM round trip, as in the
+                    // factorisation), column 0 has no update and takes the panel product alone
                     TRef invref = TRef{inv + (long long)u0 * inv_bs, inv_bs, 1, 0, 0, 0};
                     for (int k = 0; k < nt; ++k) {
-                        if (k > 0) {
-                            GemmArgs g{};
-                            g.A = W; g.B = Ls; g.C = W;
-                            g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = nt; g.mj = 1;
-                            g.k0 = 0; g.k1 = k; g.accumulate = 1; g.nbatch = ub; g.ntiles = nt;
-                            gemm(c, g, st);
-                        }
                         GemmArgs g{};
-                        g.A = W; g.B = invref; g.C = W;
-                        g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = nt; g.mj = 1;
-                        g.k0 = k; g.k1 = k + 1; g.accumulate = 0; g.nbatch = ub; g.ntiles = nt;
-                        gemm(c, g, st);
+                        g.A = W; g.C = W;
+                        g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = nt; g.mj = 1; g.nbatch = ub; g.ntiles = nt;
+                        if (k > 0 && fuse_mode()) {
+                            g.B = Ls; g.k0 = 0; g.k1 = k; g.accumulate = 1;
+                            g.fuse = 1; g.F = invref; g.fk = k;
+                            gemm(c, g, st, 3);
+                            continue;
+                        }
+                        if (k > 0) {
+                            g.B = Ls; g.k0 = 0; g.k1 = k; g.accumulate = 1;
+                            gemm(c, g, st, 3);
+                        }
+                        g.B = invref; g.k0 = k; g.k1 = k + 1; g.accumulate = 0;
+                        gemm(c, g, st, 3);
                     }
                     {   // CovITE (+ jitter) = Delta - W W^T, lower tiles
                         GemmArgs g{};
@@ -606,7 +628,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                         g.shape = 0; g.i0 = 0; g.j0 = 0; g.mi = nt; g.mj = nt; g.sym = sym_mode();
                         g.k0 = 0; g.k1 = nt; g.accumulate = 1; g.nbatch = ub; g.ntiles = (int)nlow;
                         g.order = tri_order(c, nt);
-                        gemm(c, g, st);
+                        gemm(c, g, st, 3);
                     }
                     if (want_cov) {
                         GatherCovArgs gc{};
@@ -614,13 +636,25 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                         launch_gather_cov(gc, ub, st);
                     }
                     if (want_draws) {
-                        potrf_tiles(c, Cm, nt, nt, inv2, inv_bs, io.info + s0 + u0, n, ub, st);
+                        potrf_tiles(c, Cm, nt, nt, inv2, inv_bs, io.info + s0 + u0, n, ub, st, 0, 3);
                         DrawArgs dr{};
                         dr.Lc = Cm; dr.n = n; dr.nt = nt; dr.s0 = s0 + u0; dr.S = io.S; dr.l = l; dr.L = L;
-                        dr.spp = io.spp; dr.mean = meanITE; dr.z = io.z; dr.seed = io.seed; dr.out = io.ite_draws;
+                        dr.spp = io.spp; dr.mean = meanITE; dr.z = io.z; dr.zgen = zgen; dr.seed = io.seed;
+                        if (L == 1) {     // the reference tensor directly: n x (S*spp), instance fastest
+                            dr.out = io.ite_draws;
+                            dr.obase = (long long)n * io.spp * (s0 + u0); dr.osb = (long long)n * io.spp;
+                            dr.osi = 1; dr.osd = n;
+                        } else {
+                            dr.out = dtmp;
+                            dr.obase = (long long)l * io.spp * n; dr.osb = (long long)L * io.spp * n;
+                            dr.osi = 1; dr.osd = n;
+                        }
+                        ProfScope ps(c, 2, (double)ub * io.spp, st);     // unit C: work = draws
                         launch_draws(dr, ub, st);
                     }
                 }
+                if (want_draws && L > 1)
+                    launch_draws_scatter(dtmp, io.ite_draws, n, L, io.spp, s0 + u0, ub, st);
             }
         }
     }
@@ -1309,13 +1343,13 @@ int gpslc_last_info(const gpslc_ctx* c, int32_t* info, int64_t S) {
 
 int gpslc_profile_reset(gpslc_ctx* c) {
     if (!c) return -1;
-    for (int k = 0; k < 2; ++k) { c->prof_launches[k] = 0; c->prof_ms[k] = 0; c->prof_flop[k] = 0; }
+    for (int k = 0; k < kProfClasses; ++k) { c->prof_launches[k] = 0; c->prof_ms[k] = 0; c->prof_flop[k] = 0; }
     c->prof_used = 0;
     return GPSLC_OK;
 }
 int gpslc_profile_get_class(gpslc_ctx* c, int32_t cls, int64_t* launches, double* total_ms, double* total_flop) {
     if (!c) return -1;
-    if (cls < 0 || cls > 1) return bad_arg(c, 2, "kernel class must be 0 or 1");
+    if (cls < 0 || cls >= kProfClasses) return bad_arg(c, 2, "kernel class must be 0..3");
     if (launches) *launches = c->prof_launches[cls];
     if (total_ms) *total_ms = c->prof_ms[cls];
     if (total_flop) *total_flop = c->prof_flop[cls];

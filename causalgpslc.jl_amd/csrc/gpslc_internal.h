@@ -188,11 +188,17 @@ void launch_gather_cov(const GatherCovArgs& a, int nbatch, hipStream_t st);
 struct DrawArgs {
     TRef Lc; int n, nt; long long s0, S; int l, L, spp;
     const double* mean;   // meanITE n x S x L
-    const double* z;      // n x spp x S x L or null
+    const double* z;      // caller's normals, n x spp x S x L, or null
+    double* zgen;         // z == null: workspace [nbatch][spp][n] the library's Philox normals are generated into
     unsigned long long seed;
-    double* out;          // L x n x (S*spp)
+    // element (instance i, batch element b, draw d) of this launch's level goes to out[obase + b*osb + i*osi + d*osd]:
+    // the reference tensor L x n x (S*spp) directly (L == 1), or the level-sweep staging buffer [b][l][d][i]
+    double* out;
+    long long obase, osb, osi, osd;
 };
 void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st);
+void launch_draws_scatter(const double* tmp, double* out, long long n, int L, int spp, long long s0, int nbatch,
+                          hipStream_t st);
 
 // generic multivariate-normal pieces (U-prior node and friends)
 struct DenseLoadArgs { const double* cov; int n, nt; TRef M; };   // column-major n x n -> lower tiles

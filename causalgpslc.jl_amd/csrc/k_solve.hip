@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
 // sub-tiles = 8 accumulators + 2 for K alpha).
 // ---------------------------------------------------------------------------------------
 typedef double d4s __attribute__((ext_vector_type(4)));
+typedef double d2s __attribute__((ext_vector_type(2)));
 #define IM_CC 64          // columns per staged chunk
 #define IM_RLD 80         // padded row of the R chunk (doubles): conflict-free ds_read_b64 across k rows
 #define IM_NL 64          // levels per pass
@@ -574,62 +575,165 @@ __device__ __forceinline__ double philox_normal(unsigned long long seed, unsigne
     return (e & 1ull) ? rad * sin(ang) : rad * cos(ang);
 }
 
-#define DC 8
-__global__ __launch_bounds__(256) void draws_kernel(DrawArgs a) {
-    __shared__ double zs[DC][GP_TS];
-    __shared__ double red[GP_TS][DC];
-    const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;
-    const int ib = blockIdx.x;
+// One standard normal per (instance, draw) of every unit of the sub-batch, generated ONCE per unit into a
+// workspace laid out like the caller-supplied form (z[g + n*d] per unit): thread = one Philox counter = the
+// pair of elements (2p, 2p + 1) -> (cos, sin) branch of one Box-Muller transform, exactly the values
+// philox_normal() returns for those two elements.
+__global__ __launch_bounds__(256) void normals_kernel(unsigned long long seed, long long s0, long long S, int l,
+                                                      long long n, int spp, double* out) {
+    const long long b = blockIdx.y;
+    const unsigned long long stream = (unsigned long long)(s0 + b + S * (long long)l);
+    const long long total = n * spp;                       // elements of this unit
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (2 * p >= total) return;
+    double* o = out + b * total;
+    o[2 * p] = philox_normal(seed, stream, (unsigned long long)(2 * p));
+    if (2 * p + 1 < total) o[2 * p + 1] = philox_normal(seed, stream, (unsigned long long)(2 * p + 1));
+}
+
+// The draws of one unit as a triangular matrix product on the f64 MFMA:  out[:, d] = mu + L_c z[:, d] for ALL
+// draws d of the unit in one pass over L_c (16 NQ draws per pass; spp <= 128 -> the factor is read exactly once).
+// One workgroup = one tile row of L_c (128 instances); wave w owns rows 32w..32w+31 as two row sets
+// {32w + 2j} and {32w + 2j + 1}, j = lane & 15: a lane fetches its two rows of a column with ONE 16-byte load
+// straight from HBM (every element of L_c is used by exactly one wave, so it never goes through LDS) and stores
+// its two results with one 16-byte store (16 lanes -> 256 contiguous bytes).  MFMA operands: A = z (draw index
+// = lane & 15), B = L_c (row = lane & 15), k = lane >> 4, so D[draw = 4v + (lane >> 4)][row = lane & 15].
+// z (64 columns x 16 NQ draws) is staged in LDS per half tile.  HBM-bound while 16 NQ <= 32 (one 128 KiB tile
+// per 0.5 NQ MFMA-microseconds), MFMA-bound beyond.
+#define DR_KC 64
+template <int NQ>
+__global__ __launch_bounds__(256) void draws_mfma_kernel(DrawArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double zs[];      // [DR_KC][ZLD]
+    constexpr int ND = 16 * NQ;
+    constexpr int ZLD = ND + 1;          // odd row stride: conflict-free column-wise staging writes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int ib = a.nt - 1 - (int)blockIdx.x;          // longest tile rows first
     const long long b = blockIdx.y, s = a.s0 + b;
     const long long n = a.n;
-    const long long gi = (long long)ib * GP_TS + r;
-    const unsigned long long stream = (unsigned long long)(s + a.S * a.l);
-    for (int d0 = 0; d0 < a.spp; d0 += DC) {
-        const int nd = min(DC, a.spp - d0);
-        double acc[DC];
+    const double* __restrict__ zu = a.z ? a.z + n * a.spp * (s + a.S * (long long)a.l) : a.zgen + n * a.spp * b;
+    const int r0 = 32 * wave + 2 * li;                  // this lane's two rows inside the tile: r0, r0 + 1
+    const long long gi = (long long)ib * GP_TS + r0;
+
+    for (int d0 = 0; d0 < a.spp; d0 += ND) {
+        const int nd = min(ND, a.spp - d0);
+        d4s acc[2][NQ];
 #pragma unroll
-        for (int dd = 0; dd < DC; ++dd) acc[dd] = 0.0;
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[m][q] = (d4s){0.0, 0.0, 0.0, 0.0};
         for (int jt = 0; jt <= ib; ++jt) {
-            __syncthreads();
-            for (int idx = tid; idx < DC * GP_TS; idx += 256) {
-                const int dd = idx >> 7, cc = idx & 127;
-                const long long g = (long long)jt * GP_TS + cc;
-                double v = 0.0;
-                if (dd < nd && g < n) {
-                    const long long d = d0 + dd;
-                    if (a.z) v = a.z[g + n * (d + a.spp * (s + a.S * (long long)a.l))];
-                    else v = philox_normal(a.seed, stream, (unsigned long long)(g + n * d));
+            const double* __restrict__ t = tref_tile(a.Lc, b, ib, jt) + r0;
+#pragma unroll 1
+            for (int kc = 0; kc < GP_TS / DR_KC; ++kc) {
+                // this lane's rows of the 16 column groups of the chunk: 16 independent 16-byte loads in flight
+                d2s lv[DR_KC / 4];
+#pragma unroll
+                for (int kk = 0; kk < DR_KC / 4; ++kk)
+                    lv[kk] = *reinterpret_cast<const d2s*>(t + (kc * DR_KC + 4 * kk + lq) * GP_TS);
+                __syncthreads();
+                for (int idx = tid; idx < DR_KC * ND; idx += 256) {
+                    const int k = idx & (DR_KC - 1), dd = idx / DR_KC;
+                    const long long g = (long long)jt * GP_TS + kc * DR_KC + k;
+                    zs[k * ZLD + dd] = (dd < nd && g < n) ? zu[g + n * (d0 + dd)] : 0.0;
                 }
-                zs[dd][cc] = v;
-            }
-            __syncthreads();
-            const double* t = tref_tile(a.Lc, b, ib, jt);
-#pragma unroll 4
-            for (int cq = 0; cq < 64; ++cq) {
-                const int c = h * 64 + cq;
-                const double v = t[c * GP_TS + r];
+                __syncthreads();
+                if (jt == ib) {     // diagonal tile: only the lower triangle belongs to L_c
 #pragma unroll
-                for (int dd = 0; dd < DC; ++dd) acc[dd] += v * zs[dd][c];
+                    for (int kk = 0; kk < DR_KC / 4; ++kk) {
+                        const int c = kc * DR_KC + 4 * kk + lq;
+                        if (c > r0) lv[kk].x = 0.0;
+                        if (c > r0 + 1) lv[kk].y = 0.0;
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < DR_KC / 4; ++kk) {
+                    const double* zr = zs + (4 * kk + lq) * ZLD + li;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const double zf = zr[16 * q];
+                        acc[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, lv[kk].x, acc[0][q], 0, 0, 0);
+                        acc[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, lv[kk].y, acc[1][q], 0, 0, 0);
+                    }
+                }
             }
         }
-        __syncthreads();
-        if (h == 1) {
+        // acc[m][q][v]: row r0 + m, draw d0 + 16 q + 4 v + lq
+        if (gi < n) {
+            const double mu0 = a.mean[gi + n * (s + a.S * (long long)a.l)];
+            const double mu1 = (gi + 1 < n) ? a.mean[gi + 1 + n * (s + a.S * (long long)a.l)] : 0.0;
+            double* __restrict__ ob = a.out + a.obase + b * a.osb + gi * a.osi;
 #pragma unroll
-            for (int dd = 0; dd < DC; ++dd) red[r][dd] = acc[dd];
-        }
-        __syncthreads();
-        if (h == 0 && gi < n) {
-            const double mu = a.mean[gi + n * (s + a.S * (long long)a.l)];
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int dd = 0; dd < DC; ++dd)
-                if (dd < nd)
-                    a.out[a.l + (long long)a.L * (gi + n * (s * a.spp + d0 + dd))] =
-                        mu + (acc[dd] + red[r][dd]);
+                for (int v = 0; v < 4; ++v) {
+                    const int dd = 16 * q + 4 * v + lq;
+                    if (dd < nd) {
+                        double* o = ob + (long long)(d0 + dd) * a.osd;
+                        const double x0 = mu0 + acc[0][q][v], x1 = mu1 + acc[1][q][v];
+                        if (a.osi == 1 && gi + 1 < n && ((reinterpret_cast<unsigned long long>(o) & 15ull) == 0)) {
+                            *reinterpret_cast<d2s*>(o) = (d2s){x0, x1};
+                        } else {
+                            o[0] = x0;
+                            if (gi + 1 < n) o[a.osi] = x1;
+                        }
+                    }
+                }
         }
     }
 }
+
+// Level sweep (L > 1): the draws of the sub-batch are produced level by level into tmp[b][l][d][i] (instance
+// fastest: coalesced stores) and rearranged ONCE into the reference's level-fastest tensor
+// ite[l + L*(i + n*(s*spp + d))] (src/prediction.jl:30-33) through LDS, so that both the reads (1 KiB runs along i)
+// and the writes (runs along l) are contiguous.
+#define SC_LC 32
+__global__ __launch_bounds__(256) void draws_scatter_kernel(const double* __restrict__ tmp, double* __restrict__ out,
+                                                            long long n, int L, int spp, long long s0) {
+    __shared__ double tl[SC_LC][GP_TS + 1];
+    const int tid = threadIdx.x;
+    const long long i0 = (long long)blockIdx.x * GP_TS;
+    const int d = blockIdx.y;
+    const long long b = blockIdx.z;
+    const double* src = tmp + ((b * L) * spp + d) * n;                                // + l*spp*n + i
+    double* dst = out + (long long)L * n * ((s0 + b) * spp + d);                       // + l + L*i
+    for (int l0 = 0; l0 < L; l0 += SC_LC) {
+        const int nl = min(SC_LC, L - l0);
+        __syncthreads();
+        for (int idx = tid; idx < SC_LC * GP_TS; idx += 256) {
+            const int ll = idx >> 7, ii = idx & 127;
+            if (ll < nl && i0 + ii < n) tl[ll][ii] = src[(long long)(l0 + ll) * spp * n + i0 + ii];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < SC_LC * GP_TS; idx += 256) {
+            const int ll = idx & (SC_LC - 1), ii = idx / SC_LC;
+            if (ll < nl && i0 + ii < n) dst[(l0 + ll) + (long long)L * (i0 + ii)] = tl[ll][ii];
+        }
+    }
+}
+
+template <int NQ>
+static void launch_draws_t(const DrawArgs& a, int nbatch, hipStream_t st) {
+    const int bytes = DR_KC * (16 * NQ + 1) * 8;
+    static DeviceOnce once;
+    lds_opt_in(once, (const void*)draws_mfma_kernel<NQ>, bytes);
+    hipLaunchKernelGGL((draws_mfma_kernel<NQ>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
+}
 void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st) {
-    hipLaunchKernelGGL(draws_kernel, dim3(a.nt, nbatch), dim3(256), 0, st, a);
+    if (!a.z) {     // the library's own stream: every normal of the unit is generated exactly once
+        const long long pairs = ((long long)a.n * a.spp + 1) / 2;
+        hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((pairs + 255) / 256), nbatch), dim3(256), 0, st, a.seed, a.s0,
+                           a.S, a.l, (long long)a.n, a.spp, a.zgen);
+    }
+    if (a.spp <= 16) launch_draws_t<1>(a, nbatch, st);
+    else if (a.spp <= 32) launch_draws_t<2>(a, nbatch, st);
+    else if (a.spp <= 64) launch_draws_t<4>(a, nbatch, st);
+    else launch_draws_t<8>(a, nbatch, st);
+}
+void launch_draws_scatter(const double* tmp, double* out, long long n, int L, int spp, long long s0, int nbatch,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(draws_scatter_kernel, dim3((unsigned)((n + GP_TS - 1) / GP_TS), spp, nbatch), dim3(256), 0, st,
+                       tmp, out, n, L, spp, s0);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -74,6 +74,24 @@ def removeAdjacent(v):
     return out
 
 
+def _parse_csv_column(vals):
+    """The element type CSV.jl's inference would give a column: int, else float, else the strings themselves."""
+    vals = list(vals)
+    if all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in vals):
+        return [int(v) for v in vals]
+    if all(isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, bool) for v in vals):
+        return [float(v) for v in vals]
+    strs = [str(v).strip() for v in vals]
+    try:
+        return [int(v) for v in strs]
+    except ValueError:
+        pass
+    try:
+        return [float(v) for v in strs]
+    except ValueError:
+        return strs
+
+
 def prepareData(data, confounderEps=1.0e-13, confounderCov=1.0):
     """src/data.jl:20-70: CSV path (or dict of columns) -> SigmaU, obj, X, T, Y; rows sorted by `obj`
     (stable), covariates = every column that is not T / Y / obj."""
@@ -87,8 +105,12 @@ def prepareData(data, confounderEps=1.0e-13, confounderCov=1.0):
     order = np.arange(n)
     SigmaU = obj = None
     if "obj" in cols:
-        order = np.array(sorted(range(n), key=lambda i: cols["obj"][i]))   # DataFrames.sort! is stable
-        obj = [cols["obj"][i] for i in order]
+        # CSV.jl has already typed the column when DataFrames.sort! (src/data.jl:24) sees it: Int64 when every
+        # value parses as an integer, else Float64 when every value parses as a number, else String — numeric
+        # labels therefore sort numerically (1, 2, ..., 10), not lexicographically (1, 10, 11, ..., 2)
+        keys = _parse_csv_column(cols["obj"])
+        order = np.array(sorted(range(n), key=lambda i: keys[i]))          # DataFrames.sort! is stable
+        obj = [keys[i] for i in order]
         counts = {}
         for o in obj:
             counts[o] = counts.get(o, 0) + 1

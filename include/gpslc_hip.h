@@ -215,10 +215,12 @@ int gpslc_pack_load(const char* path, int64_t s0, int64_t s1, double* X, double*
 
 /* ---- measurement hooks (bench.py, profiles/) ----------------------------------------- */
 
-/* Accumulated HIP-event statistics of the f64-MFMA tile-update kernel since the last reset, recorded when
- * the ctx was created with GPSLC_FLAG_PROFILE: launches, total device milliseconds, total algorithmic flop.
- * Kernel class 0 = tile_gemm_nt_kernel<1, 0, 0> (trailing updates and SYRKs: the dominant kernel),
- * class 1 = tile_gemm_nt_kernel<1, 0, 1> (in-panel column update fused with the panel solve).
+/* Accumulated HIP-event statistics since the last reset, recorded (on the launching stream) when the ctx was
+ * created with GPSLC_FLAG_PROFILE: launches, total device milliseconds, total algorithmic work.  Kernel classes:
+ *   0  tile_gemm_nt_kernel<1, 0, 0> in the factorisation of A (trailing updates: the dominant kernel)   work = flop
+ *   1  tile_gemm_nt_kernel<1, 0, 1> in the factorisation of A (in-panel column update + panel solve)    work = flop
+ *   2  the predictive-draw kernels of a launch_draws call (normal generation + triangular product)      work = draws
+ *   3  every f64-MFMA tile-update launch of the full-ITE-covariance path (W solve, SYRK, factor)        work = flop
  * gpslc_profile_get is class 0. */
 int gpslc_profile_reset(gpslc_ctx* ctx);
 int gpslc_profile_get(gpslc_ctx* ctx, int64_t* launches, double* total_ms, double* total_flop);

@@ -1,0 +1,122 @@
+"""ABI edges added in round 2: the Y override of the :Y score, device-pointer forms of
+rbfKernelLog / processCov, node scores on a ctx without data, several ctxs driven from several threads, and that
+the production library ignores the measurement switches of the environment."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import cases
+import gpslc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_y_logpdf_scores_the_value_it_is_given(gp):
+    """HipYNormal.logpdf(y, ...): Gen hands the distribution the value to score; it is the ctx's
+    Y only while :Y is constrained to the data (src/model_likelihood.jl:89)."""
+    c = cases.make_case(150, "UX", False, S=3, seed=12)
+    g = cases.gpslc_object(gp, c)
+    y2 = np.random.default_rng(1).standard_normal(150)
+    lp_data = gp.yLogpdf(g)
+    lp_other = gp.yLogpdf(g, Y_override=y2)
+    lp_same = gp.yLogpdf(g, Y_override=c["Y"])
+    assert np.array_equal(lp_same, lp_data)
+    for s, p in enumerate(cases.samples_of(c)):
+        ref = orc.y_logpdf(p.uyLS, p.xyLS, p.tyLS, p.yScale, p.yNoise, p.U, c["X"], c["T"], y2)
+        assert abs(lp_other[s] - ref) <= 1e-11 * abs(ref)
+    assert not np.allclose(lp_other, lp_data)
+    # and the override does not stick
+    assert np.array_equal(gp.yLogpdf(g), lp_data)
+
+
+def test_rbf_log_and_process_cov_device_pointer_forms(gp):
+    import torch
+    n, d = 130, 3
+    rng = np.random.default_rng(3)
+    A, B, ls = rng.standard_normal((n, d)), rng.standard_normal((n, d)), np.array([0.7, 1.3, 2.1])
+    ref = gp.rbfKernelLog(A, B, ls)                       # host-pointer form
+    dev = torch.device("cuda", 0)
+
+    def up(x):
+        return torch.from_numpy(np.ascontiguousarray(x.reshape(-1, order="F"))).to(dev)
+
+    dA, dB, dl = up(A), up(B), up(ls)
+    out = torch.empty(n * n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    ctx = gp.Context(1, 0, 0)
+    p = lambda t: C.c_void_p(t.data_ptr())               # noqa: E731
+    ctx.check(ctx.lib.gpslc_rbf_log_dev(ctx.h, p(dA), p(dB), n, d, p(dl), 3, p(out)))
+    assert np.array_equal(out.cpu().numpy().reshape(n, n, order="F"), ref)
+    ctx.check(ctx.lib.gpslc_process_cov_dev(ctx.h, p(out), n, 1.7, 0.3, p(out)))     # in place
+    assert np.array_equal(out.cpu().numpy().reshape(n, n, order="F"), gp.processCov(ref, 1.7, 0.3))
+    assert ctx.lib.gpslc_rbf_log_dev(ctx.h, None, p(dB), n, d, p(dl), 3, p(out)) == -2
+    assert ctx.lib.gpslc_process_cov_dev(ctx.h, p(out), 0, 1.0, 0.0, p(out)) == -3
+
+
+def test_scalar_kernel_logit_expit(gp):
+    # test/kernel.jl: the scalar form is the matrix form's entry; src/kernel.jl:46-49
+    x, y, ls = np.array([1.0, 2.0, 3.0]), np.array([0.5, 2.5, 1.0]), np.array([1.0, 2.0, 0.5])
+    assert gp.rbfKernelLogScalar(x, y, ls) == orc.rbf_kernel_log_scalar(x, y, ls)
+    assert gp.rbfKernelLogScalar(2.0, 5.0, 3.0) == -1.0
+    with pytest.raises(AssertionError):
+        gp.rbfKernelLogScalar(x, y, np.ones(2))
+    assert gp.logit(0.5) == 0.0 and gp.expit(0.0) == 0.5
+    assert abs(gp.expit(gp.logit(0.3)) - 0.3) < 1e-15
+
+
+def test_node_scores_work_on_a_ctx_without_data(gp):
+    n = 140
+    rng = np.random.default_rng(8)
+    F, tgt = rng.standard_normal((n, 2)), rng.standard_normal(n)
+    ctx = gp.Context(n, 0, 0)                             # gpslc_set_data never called
+    out = gp.gpLogpdf(F, [0.9, 1.4], [1.2], [0.5], tgt, ctx=ctx)
+    cov = orc.process_cov(orc.rbf_kernel_log(F, F, np.array([0.9, 1.4])), 1.2, 0.5)
+    ref = orc.mvnormal_logpdf(tgt, cov)
+    assert abs(out[0] - ref) <= 1e-11 * abs(ref)
+
+
+def test_two_ctxs_from_two_threads_are_bit_identical(gp):
+    """One ctx per thread on the same device: no shared mutable state in the library."""
+    c = cases.make_case(260, "UX", False, S=6, seed=77)
+    base = gp.predict(cases.gpslc_object(gp, c), c["doTs"], want_mean_ite=True)
+    res = [None, None]
+
+    def work(i):
+        g = cases.gpslc_object(gp, c)
+        for _ in range(3):
+            res[i] = gp.predict(g, c["doTs"], want_mean_ite=True)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for r in res:
+        for a, b in zip(r, base):
+            assert np.array_equal(a, b)
+
+
+def test_production_library_ignores_measurement_switches():
+    """GPSLC_GEMM_DIAG & co. exist only in the -DGPSLC_DIAG build (tools/): with them set, the production library
+    returns the same bits."""
+    code = ("import sys; sys.path[:0] = [%r, %r]; import numpy as np, cases, causalgpslc_jl_amd as gp;"
+            "c = cases.make_case(300, 'UX', False, S=3, seed=5);"
+            "ms, vs, mi = gp.predict(cases.gpslc_object(gp, c), c['doTs'], want_mean_ite=True);"
+            "sys.stdout.write(ms.tobytes().hex() + vs.tobytes().hex())") % (ROOT, os.path.join(ROOT, "tests"))
+    env0 = {k: v for k, v in os.environ.items() if not k.startswith("GPSLC_")}
+    env0["PYTHONPATH"] = os.path.join(ROOT, "oracle")
+    env1 = dict(env0, GPSLC_GEMM_DIAG="2", GPSLC_GEMM_QUEUE="0", GPSLC_SYRK_DIAG="0", GPSLC_FUSE_PANEL="0",
+                GPSLC_GEMM_SLOTS="7", GPSLC_ORDER_BLOCK="1", GPSLC_GEMM_DBG="9")
+    a = subprocess.run([sys.executable, "-c", code], env=env0, capture_output=True, text=True, timeout=600)
+    b = subprocess.run([sys.executable, "-c", code], env=env1, capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-500:], b.stderr[-500:])
+    assert a.stdout == b.stdout and len(a.stdout) > 0
+    syms = subprocess.run(["nm", "-C", os.path.join(ROOT, "causalgpslc.jl_amd", "csrc", "libgpslc_hip.so")],
+                          capture_output=True, text=True).stdout
+    inst = sorted(set(l.split("tile_gemm_nt_kernel")[1].split("(")[0] for l in syms.splitlines()
+                      if "__device_stub__tile_gemm_nt_kernel" in l))
+    assert all(i.split(",")[1].strip() == "0" for i in inst), inst     # no timing-only (DIAG != 0) instantiation

@@ -82,6 +82,47 @@ def test_config3_n4096_d8_nu2(gp):
     assert np.allclose(ms2, ms, rtol=1e-11, atol=1e-14) and np.allclose(vs2, vs, rtol=1e-9, atol=1e-14)
 
 
+def test_config3_n4096_against_the_literal_restatement(gp):
+    """BASELINE configs[2] against the LITERAL restatement of the reference algorithm (5 log-kernels, three
+    symmetric-indefinite solves, four block products: src/likelihood.jl:8-52, src/estimation.jl:36-50, 116-121)
+    for two posterior samples — the structured oracle shares the GPU path's algebra, the literal one does not.
+    Tolerances: SURVEY §8d."""
+    n, D, K, S = 4096, 8, 2, 8
+    g, data = _obj(gp, n, D, K, S)
+    X, T, Y, post = data
+    doTs = gp.synth.levels(T, 1)
+    ms, vs, mi = gp.predict(g, doTs, want_mean_ite=True)
+    for s in (0, 5):
+        p = _sample(post, s, D, K)
+        M, Cv = orc.ite_distributions([p], X, T, Y, float(doTs[0]))
+        rm, rv = orc.conditional_sate(M[0], Cv[0])
+        assert abs(ms[s, 0] - rm) <= 1e-6 * abs(rm) + 1e-12
+        assert abs(vs[s, 0] - rv) <= 1e-6 * abs(rv) + 1e-9 * p.yScale
+        assert np.max(np.abs(mi[:, s, 0] - M[0])) <= 1e-6 * np.max(np.abs(M[0])) + 1e-12
+        del M, Cv
+
+
+def test_unit_b_with_draws_n1024_default_jitter(gp):
+    """Full ITE covariance + its factor + draws at N=1024 with the reference's 1e-10 jitter
+    (src/hyperparameters.jl:92): the factorisation of CovITE + 1e-10 I succeeds (info == 0) and the draws with the
+    caller's normals match the literal restatement (Cholesky per draw, src/estimation.jl:95-109) within
+    1e-8 ||L_c||."""
+    n, D, K, S, spp = 1024, 4, 1, 2, 3
+    g, (X, T, Y, post) = _obj(gp, n, D, K, S)
+    doT = float(gp.synth.levels(T, 1)[0])
+    z = np.random.default_rng(5).standard_normal((n, S * spp))
+    out = gp.sampleITE(g, doT, samplesPerPosterior=spp, z=z)
+    assert not g.ctx().last_info(S).any()
+    smp = [_sample(post, s, D, K) for s in range(S)]
+    M, Cv = orc.ite_distributions(smp, X, T, Y, doT)
+    ref = orc.ite_samples(M, Cv, spp, z)
+    for s in range(S):
+        lc_norm = np.sqrt(np.linalg.eigvalsh(Cv[s])[-1])          # ||L_c||_2 = sqrt(lambda_max(CovITE + jitter))
+        for d in range(spp):
+            col = s * spp + d
+            assert np.linalg.norm(out[:, col] - ref[:, col]) <= 1e-8 * lc_norm * np.linalg.norm(z[:, col])
+
+
 def test_permutation_invariance_n1024(gp):
     n, D, K, S = 1024, 4, 1, 6
     g, (X, T, Y, post) = _obj(gp, n, D, K, S, seed=77)
@@ -118,6 +159,26 @@ def test_config5_n16384_d16_nu4_binary(gp):
     # binary T: an instance already at the intervention level has r_j == e_ij for its own row only; the
     # ITE of "doT = its own treatment" is not zero in general, but MeanSATE(0) and MeanSATE(1) differ
     assert np.all(np.abs(ms[:, 0] - ms[:, 1]) > 0)
+
+
+def test_config5_mixed_precision_n16384_against_the_fp64_oracle(gp):
+    """BASELINE configs[4] in its stated mode: N=16384 D=16 nU=4 binary treatment, fp32 kernel build + fp64
+    Cholesky (GPSLC_FLAG_FP32_KERNEL), against the structured oracle evaluated entirely in fp64.
+    The 1e-6 relative target of north_star holds for the SATE mean; the variance carries the mixed absolute term
+    of SURVEY §8d."""
+    n, D, K, S = 16384, 16, 4, 2
+    X, T, Y, objid = gp.synth.make_dataset(n, D, binary_t=True)
+    post = gp.synth.make_posterior(n, D, K, S, objid)
+    g = gp.GPSLCObject(X, T, Y, post["U"], post["uyLS"], post["xyLS"], post["tyLS"], post["yNoise"], post["yScale"],
+                       fp32_kernel=True)
+    doTs = np.array([0.0, 1.0])
+    ms, vs, mi = gp.predict(g, doTs, want_mean_ite=True)
+    assert np.max(np.abs(mi.mean(axis=0) - ms)) <= 1e-9 * np.max(np.abs(ms)) + 1e-13
+    p = _sample(post, 1, D, K)
+    rm, rv, _, _ = orc.structured_sate(p, X, T, Y, doTs)
+    for l in range(2):
+        assert abs(ms[1, l] - rm[l]) <= 1e-6 * abs(rm[l]) + 1e-12, (ms[1, l], rm[l])
+        assert abs(vs[1, l] - rv[l]) <= 1e-6 * abs(rv[l]) + 1e-9 * p.yScale, (vs[1, l], rv[l])
 
 
 def test_config4_shape_n4096_64_levels(gp):
