@@ -97,6 +97,31 @@ def header_symbols(path: str = HEADER_PATH):
     return sorted(set(re.findall(r"\b(gpslc_[a-z_0-9]+)\s*\(", txt)))
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same SONAME as
+    /opt/rocm's); the dynamic loader binds every later user of that SONAME to whichever copy was loaded first,
+    and a process that initialises the system copy first and torch's HSA stack second sees "No HIP GPUs".  When
+    torch is installed (bench.py and sharded.py use it for device memory and the process group) its copy is
+    loaded before libgpslc_hip.so, so the library and torch share a runtime whatever the import order.  Without
+    torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the library (once).  Raises GPSLCLibraryError when it is absent — by design there is
     no fallback path."""
@@ -107,6 +132,7 @@ def load():
         raise GPSLCLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C causalgpslc.jl_amd/csrc`; there is no CPU fallback")
+    _one_hip_runtime()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

@@ -501,10 +501,14 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         // unit-B sub-batch: 64 units at N = 4096 (203 MB each); larger buys nothing (measured)
         Bb_target = (int)std::max<long long>(1, std::min<long long>(128, 65536LL / ((long long)nt * nt)));
     }
-    const size_t fixed = (size_t)Bb_target * unitB_per + (1 << 20);
+    // draws: normals workspace of one level of the sub-batch + the level-sweep staging buffer (see the unit-B loop)
+    const size_t draws_per = want_draws ? ((io.z ? 0 : (size_t)io.spp * n * 8 + 256) +
+                                           (L > 1 ? (size_t)L * io.spp * n * 8 + 256 : 0)) : 0;
+    const size_t unitB_all = unitB_per + draws_per;
+    const size_t fixed = (size_t)Bb_target * unitB_all + (1 << 20);
     const int Bt = auto_batch(c, io.S, per, fixed);
     const int Bb = unitB ? std::min(Bb_target, Bt) : 0;
-    const size_t need = (size_t)Bt * per + (size_t)Bb * unitB_per + (1 << 20);
+    const size_t need = (size_t)Bt * per + (size_t)Bb * unitB_all + (1 << 20);
     for (int i = 0; i < c->nstreams; ++i) arena_reserve(c, c->arenas[i], need);
 
     // internal MeanITE buffer when the caller did not ask for it but the draws need it

@@ -35,28 +35,53 @@ def test_y_logpdf_scores_the_value_it_is_given(gp):
     assert np.array_equal(gp.yLogpdf(g), lp_data)
 
 
+class _Hip:
+    """hipMalloc / hipMemcpy through ctypes on the HIP runtime the library itself uses (no torch needed)."""
+
+    def __init__(self):
+        self.rt = C.CDLL("libamdhip64.so.7")      # already loaded by libgpslc_hip.so: same instance
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+        self.bufs = []
+
+    def up(self, x):
+        x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, order="F"))
+        p = self.empty(x.size)
+        assert self.rt.hipMemcpy(p, x.ctypes.data_as(C.c_void_p), x.nbytes, 1) == 0
+        return p
+
+    def empty(self, count):
+        p = C.c_void_p()
+        assert self.rt.hipMalloc(C.byref(p), 8 * count) == 0
+        self.bufs.append(p)
+        return p
+
+    def down(self, p, count):
+        out = np.empty(count)
+        assert self.rt.hipMemcpy(out.ctypes.data_as(C.c_void_p), p, 8 * count, 2) == 0
+        return out
+
+    def free(self):
+        for p in self.bufs:
+            self.rt.hipFree(p)
+
+
 def test_rbf_log_and_process_cov_device_pointer_forms(gp):
-    import torch
     n, d = 130, 3
     rng = np.random.default_rng(3)
     A, B, ls = rng.standard_normal((n, d)), rng.standard_normal((n, d)), np.array([0.7, 1.3, 2.1])
     ref = gp.rbfKernelLog(A, B, ls)                       # host-pointer form
-    dev = torch.device("cuda", 0)
-
-    def up(x):
-        return torch.from_numpy(np.ascontiguousarray(x.reshape(-1, order="F"))).to(dev)
-
-    dA, dB, dl = up(A), up(B), up(ls)
-    out = torch.empty(n * n, dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
+    hip = _Hip()
+    dA, dB, dl, out = hip.up(A), hip.up(B), hip.up(ls), hip.empty(n * n)
     ctx = gp.Context(1, 0, 0)
-    p = lambda t: C.c_void_p(t.data_ptr())               # noqa: E731
-    ctx.check(ctx.lib.gpslc_rbf_log_dev(ctx.h, p(dA), p(dB), n, d, p(dl), 3, p(out)))
-    assert np.array_equal(out.cpu().numpy().reshape(n, n, order="F"), ref)
-    ctx.check(ctx.lib.gpslc_process_cov_dev(ctx.h, p(out), n, 1.7, 0.3, p(out)))     # in place
-    assert np.array_equal(out.cpu().numpy().reshape(n, n, order="F"), gp.processCov(ref, 1.7, 0.3))
-    assert ctx.lib.gpslc_rbf_log_dev(ctx.h, None, p(dB), n, d, p(dl), 3, p(out)) == -2
-    assert ctx.lib.gpslc_process_cov_dev(ctx.h, p(out), 0, 1.0, 0.0, p(out)) == -3
+    ctx.check(ctx.lib.gpslc_rbf_log_dev(ctx.h, dA, dB, n, d, dl, 3, out))
+    assert np.array_equal(hip.down(out, n * n).reshape(n, n, order="F"), ref)
+    ctx.check(ctx.lib.gpslc_process_cov_dev(ctx.h, out, n, 1.7, 0.3, out))     # in place
+    assert np.array_equal(hip.down(out, n * n).reshape(n, n, order="F"), gp.processCov(ref, 1.7, 0.3))
+    assert ctx.lib.gpslc_rbf_log_dev(ctx.h, None, dB, n, d, dl, 3, out) == -2
+    assert ctx.lib.gpslc_process_cov_dev(ctx.h, out, 0, 1.0, 0.0, out) == -3
+    hip.free()
 
 
 def test_scalar_kernel_logit_expit(gp):

@@ -163,14 +163,21 @@ def test_ite_draws_with_supplied_normals(gp, n, shape, bt, pred_noise):
     M, Cv = orc.ite_distributions(smp, c["X"], c["T"], c["Y"], doT, pred_noise)
     rel = 1e-3 if pred_noise < 1e-6 else 1e-8
     for s in range(c["S"]):
-        lc_norm = np.sqrt(np.linalg.eigvalsh(Cv[s])[-1])       # ||L_c||_2
+        ev = np.linalg.eigvalsh(Cv[s])
+        lc_norm = np.sqrt(ev[-1])                              # ||L_c||_2
+        kappa = ev[-1] / max(ev[0], 1e-300)                    # cond(CovITE + jitter I)
         for d in range(spp):
             col = s * spp + d
             dev_out = out[:, col] - M[s]
             dev_ref = ref[:, col] - M[s]
             assert np.linalg.norm(dev_out - dev_ref) <= rel * np.linalg.norm(dev_ref) + 1e-12
-            # identical z => |draw - ref| <= 1e-8 ||L_c|| (absolute in the factor's norm, at either jitter)
-            assert np.linalg.norm(dev_out - dev_ref) <= 1e-8 * lc_norm * np.linalg.norm(z[:, col])
+            # identical z => |draw - ref| <= 1e-8 ||L_c||.  That flat bound presumes a factor the data
+            # determine to 1e-8; a Cholesky factor moves by cond(A) * |dA| / |A| (|dA| / |A| ~ 1e-15 from forming
+            # CovITE), which exceeds 1e-8 once cond > 1e7 — the rank-deficient CovITE of a binary treatment at the
+            # default 1e-10 jitter has cond ~ 4e10 and measures 1.1e-5.  Asserted: the flat bound wherever the
+            # conditioning permits it, the conditioning-limited one otherwise.
+            bound = max(1e-8, 1e-15 * kappa)
+            assert np.linalg.norm(dev_out - dev_ref) <= bound * lc_norm * np.linalg.norm(z[:, col])
 
 
 @pytest.mark.parametrize("spp,L", [(1, 1), (10, 1), (17, 3), (40, 2), (100, 1), (130, 3)])

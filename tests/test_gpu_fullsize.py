@@ -173,7 +173,8 @@ def test_config5_mixed_precision_n16384_against_the_fp64_oracle(gp):
                        fp32_kernel=True)
     doTs = np.array([0.0, 1.0])
     ms, vs, mi = gp.predict(g, doTs, want_mean_ite=True)
-    assert np.max(np.abs(mi.mean(axis=0) - ms)) <= 1e-9 * np.max(np.abs(ms)) + 1e-13
+    # the two SATE paths evaluate the fp32 kernel independently (Gram build vs the MeanITE pass): fp32 rounding apart
+    assert np.max(np.abs(mi.mean(axis=0) - ms)) <= 1e-6 * np.max(np.abs(ms)) + 1e-13
     p = _sample(post, 1, D, K)
     rm, rv, _, _ = orc.structured_sate(p, X, T, Y, doTs)
     for l in range(2):
