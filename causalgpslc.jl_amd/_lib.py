@@ -59,6 +59,7 @@ SIGNATURES = {
     "gpslc_process_cov_dev": (C.c_int, [C.c_void_p, _D, C.c_int64, C.c_double, C.c_double, _D]),
     "gpslc_y_logpdf": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D, _D, _D, _D, _D, _D]),
     "gpslc_gp_logpdf": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _D, C.c_int32, _D, _D, _D, _D, C.c_int32, _D]),
+    "gpslc_nodes_logpdf": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, _D]),
     "gpslc_mvn_logpdf": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D]),
     "gpslc_predict": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D, _D, _D, C.c_int32, _D, C.c_double,
                                 C.c_int32, C.c_uint64, _D, _D, _D, _D, _D]),
@@ -80,6 +81,12 @@ SIGNATURES = {
     "gpslc_pack_read_header": (C.c_int, [C.c_char_p, C.c_void_p]),
     "gpslc_pack_load": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, _D, _D, _D, _D, _D, _D, _D, _D, _D]),
 }
+
+
+class Node(C.Structure):
+    """gpslc_node (include/gpslc_hip.h)."""
+    _fields_ = [("nF", C.c_int32), ("reserved", C.c_int32), ("F", C.c_void_p), ("ls", C.c_void_p),
+                ("scale", C.c_double), ("noise", C.c_double), ("target", C.c_void_p)]
 
 
 class PackHeader(C.Structure):

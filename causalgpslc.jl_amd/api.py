@@ -505,6 +505,37 @@ def gpLogpdf(F, LS, scale, noise, target, ctx: Optional[Context] = None):
     return out
 
 
+def nodesLogpdf(nodes, ctx: Context):
+    """The fused whole-model score (gpslc_nodes_logpdf): ``nodes`` is a sequence of (F, LS, scale, noise, target)
+    — F (n, nF) or None, LS (nF,), scalars, target (n,) — one per Gen address to re-score (:X => k => :X, :T /
+    :logitT, :Y with F = [U | X | T]; src/model_likelihood.jl:13-120).  One call, and for n <= ~160 one kernel
+    launch, whatever the nodes' feature counts.  Returns the log-densities (len(nodes),)."""
+    cnt = len(nodes)
+    arr = (_lib.Node * max(cnt, 1))()
+    keep = []
+    for i, (F, LS, scale, noise, target) in enumerate(nodes):
+        tg = _f(target, (ctx.n,))
+        if F is None or np.asarray(F).size == 0:
+            Fa, ls, nF = None, None, 0
+        else:
+            Fa = _f(F)
+            if Fa.ndim == 1:
+                Fa = Fa[:, None]
+            nF = Fa.shape[1]
+            ls = np.ascontiguousarray(np.asarray(LS, dtype=np.float64).reshape(nF))
+        keep.append((Fa, ls, tg))
+        arr[i].nF = nF
+        arr[i].F = None if Fa is None else Fa.ctypes.data
+        arr[i].ls = None if ls is None else ls.ctypes.data
+        arr[i].scale = float(scale)
+        arr[i].noise = float(noise)
+        arr[i].target = tg.ctypes.data
+    out = np.empty(cnt)
+    st = ctx.lib.gpslc_nodes_logpdf(ctx.h, cnt, C.cast(arr, C.c_void_p), _p(out))
+    ctx.check(st)
+    return out
+
+
 def mvnLogpdf(cov, x, covscale=None, ctx: Optional[Context] = None):
     """log N(x_s; 0, covscale_s * cov): the :U => u => :U node scores (uCov = SigmaU * uNoise,
     src/model_likelihood.jl:4-10, src/model_prior.jl:27-30).  ``cov=None`` re-uses the factor cached in

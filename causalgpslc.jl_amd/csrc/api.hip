@@ -118,6 +118,11 @@ struct gpslc_ctx {
     std::vector<int*> queues;      // one ticket-counter block (16 ints) per stream slot, see GemmArgs::queue
     Arena scratch;                 // call-level buffers (internal MeanITE of a draws-only call, ...)
     PoolArena io;                  // staging of the host-pointer entry points and per-call info words
+    // single-launch small-n node scores (k_small.hip): pinned, device-visible host staging (descriptors, inputs,
+    // results) and host copies of the ctx's data for assembling the :Y node's feature block
+    char* pin = nullptr;
+    size_t pin_bytes = 0;
+    std::vector<double> hX, hT, hY;
     std::string err;
     std::vector<int32_t> last_info;
     // cached factor of the last dense covariance given to gpslc_mvn_logpdf (SigmaU is constant per data set)
@@ -746,6 +751,92 @@ int check_common(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, c
     return 0;
 }
 
+// ---- single-launch small-n node scores ----------------------------------------------------------------------------
+constexpr size_t kLdsBytes = 160 * 1024;
+
+struct HostNode {            // host view of one node (gpslc_node with plain pointers)
+    int nF;
+    const double* F[2];      // up to two column groups + one extra column are concatenated into the feature block:
+    int nFpart[2];           //   F[0] (nFpart[0] columns), F[1] (nFpart[1] columns), then `col` (one column) if non-null
+    const double* col;
+    const double* ls[2];     // lengthscales of the two groups; ls_col for the extra column
+    double ls_col;
+    double scale, noise;
+    const double* target;
+};
+
+bool small_path_fits(const gpslc_ctx* c, int nF_max) {
+    return small_gp_lds_bytes((int)c->n, nF_max) <= kLdsBytes;
+}
+
+void pin_reserve(gpslc_ctx* c, size_t bytes) {
+    if (c->pin_bytes >= bytes) return;
+    if (c->pin) { HC(hipDeviceSynchronize()); HC(hipHostFree(c->pin)); c->pin = nullptr; c->pin_bytes = 0; }
+    void* p = nullptr;
+    bytes = (bytes + 4095) & ~size_t(4095);
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); throw std::bad_alloc(); }
+    c->pin = static_cast<char*>(p);
+    c->pin_bytes = bytes;
+}
+
+// scores `count` nodes in ONE launch; logdet/quad/info per node come back through the pinned buffer.
+// Returns the first failing pivot (0 = all fine); logpdf[i] = -(n log 2pi + logdet_i + quad_i) / 2.
+int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* logpdf) {
+    ensure_streams(c);
+    const size_t n = (size_t)c->n;
+    size_t doubles = 0;
+    int nF_max = 0;
+    for (int i = 0; i < count; ++i) {
+        doubles += n * nodes[i].nF + nodes[i].nF + n;
+        nF_max = std::max(nF_max, nodes[i].nF);
+    }
+    const size_t off_out = ((size_t)count * sizeof(SmallNode) + 63) & ~size_t(63);
+    const size_t off_data = off_out + (size_t)count * 4 * sizeof(double);
+    pin_reserve(c, off_data + doubles * sizeof(double));
+    void* dbase = nullptr;
+    HC(hipHostGetDevicePointer(&dbase, c->pin, 0));
+    char* dev = static_cast<char*>(dbase);
+    SmallNode* hn = reinterpret_cast<SmallNode*>(c->pin);
+    double* hout = reinterpret_cast<double*>(c->pin + off_out);
+    double* hd = reinterpret_cast<double*>(c->pin + off_data);
+    double* dd = reinterpret_cast<double*>(dev + off_data);
+    size_t o = 0;
+    for (int i = 0; i < count; ++i) {
+        const HostNode& h = nodes[i];
+        SmallNode& sn = hn[i];
+        sn.nF = h.nF; sn.pad_ = 0; sn.scale = h.scale; sn.noise = h.noise;
+        sn.F = dd + o;
+        for (int g = 0; g < 2; ++g)
+            if (h.nFpart[g] > 0) { memcpy(hd + o, h.F[g], n * h.nFpart[g] * sizeof(double)); o += n * h.nFpart[g]; }
+        if (h.col) { memcpy(hd + o, h.col, n * sizeof(double)); o += n; }
+        sn.ls = dd + o;
+        for (int g = 0; g < 2; ++g)
+            if (h.nFpart[g] > 0) { memcpy(hd + o, h.ls[g], h.nFpart[g] * sizeof(double)); o += h.nFpart[g]; }
+        if (h.col) hd[o++] = h.ls_col;
+        sn.target = dd + o;
+        memcpy(hd + o, h.target, n * sizeof(double));
+        o += n;
+    }
+    SmallArgs a{};
+    a.nodes = reinterpret_cast<const SmallNode*>(dev);
+    a.n = (int)n; a.NB = (int)((n + 15) / 16);
+    a.out = reinterpret_cast<double*>(dev + off_out);
+    hipStream_t st = c->streams[0];
+    launch_small_gp(a, count, nF_max, st);
+    HC(hipGetLastError());
+    HC(hipStreamSynchronize(st));
+    const double l2pi = 1.8378770664093454835606594728112;
+    int first = 0;
+    c->last_info.resize((size_t)count);
+    for (int i = 0; i < count; ++i) {
+        const int info = (int)hout[4 * i + 2];
+        c->last_info[i] = info;
+        if (info != 0 && first == 0) first = info;
+        logpdf[i] = -0.5 * ((double)n * l2pi + hout[4 * i] + hout[4 * i + 1]);
+    }
+    return first;
+}
+
 }  // namespace
 
 extern "C" {
@@ -799,6 +890,7 @@ int gpslc_destroy(gpslc_ctx* c) {
     for (int* q : c->queues) if (q) (void)hipFree(q);
     if (c->scratch.base) (void)hipFree(c->scratch.base);
     c->io.release();
+    if (c->pin) (void)hipHostFree(c->pin);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto p : c->tri_order) if (p) (void)hipFree(p);
     if (c->mvn_tiles) (void)hipFree(c->mvn_tiles);
@@ -819,10 +911,14 @@ static int set_data_impl(gpslc_ctx* c, const double* X, const double* T, const d
         if (c->nX > 0) HC(hipMemcpy(c->dX, X, sizeof(double) * c->n * c->nX, kind));
         HC(hipMemcpy(c->dT, T, sizeof(double) * c->n, kind));
         HC(hipMemcpy(c->dY, Y, sizeof(double) * c->n, kind));
-        std::vector<double> hT(c->n);
-        HC(hipMemcpy(hT.data(), c->dT, sizeof(double) * c->n, hipMemcpyDeviceToHost));
+        c->hX.resize((size_t)c->n * c->nX);
+        c->hT.resize(c->n);
+        c->hY.resize(c->n);
+        if (c->nX > 0) HC(hipMemcpy(c->hX.data(), c->dX, sizeof(double) * c->n * c->nX, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(c->hT.data(), c->dT, sizeof(double) * c->n, hipMemcpyDeviceToHost));
+        HC(hipMemcpy(c->hY.data(), c->dY, sizeof(double) * c->n, hipMemcpyDeviceToHost));
         c->binary_t = true;
-        for (double t : hT) if (t != 0.0 && t != 1.0) { c->binary_t = false; break; }
+        for (double t : c->hT) if (t != 0.0 && t != 1.0) { c->binary_t = false; break; }
         c->has_data = true;
         return GPSLC_OK;
     });
@@ -1041,6 +1137,25 @@ int gpslc_y_logpdf(gpslc_ctx* c, int64_t S, const double* U, const double* X_or_
     if (rc) return rc;
     if (!logpdf) return bad_arg(c, 11, "logpdf is NULL");
     if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
+    if (!(c->flags & GPSLC_FLAG_FP32_KERNEL) && small_path_fits(c, c->nU + c->nX + 1) && S <= 4096) {
+        // small n: every parameter set is one workgroup of ONE launch (k_small.hip); T enters as a feature column
+        return guarded(c, [&]() {
+            const size_t n = (size_t)c->n;
+            std::vector<HostNode> hn((size_t)S);
+            for (int64_t s = 0; s < S; ++s) {
+                HostNode& h = hn[s];
+                h = HostNode{};
+                h.nF = c->nU + c->nX + 1;
+                h.F[0] = c->nU ? U + s * n * c->nU : nullptr; h.nFpart[0] = c->nU; h.ls[0] = c->nU ? uyLS + s * c->nU : nullptr;
+                h.F[1] = c->nX ? (X_or_null ? X_or_null : c->hX.data()) : nullptr; h.nFpart[1] = c->nX;
+                h.ls[1] = c->nX ? xyLS + s * c->nX : nullptr;
+                h.col = c->hT.data(); h.ls_col = tyLS[s];
+                h.scale = yScale[s]; h.noise = yNoise[s];
+                h.target = Y_or_null ? Y_or_null : c->hY.data();
+            }
+            return small_nodes_logpdf(c, (int)S, hn.data(), logpdf);
+        });
+    }
     return guarded(c, [&]() {
         const size_t n = (size_t)c->n;
         c->io.reset();
@@ -1066,6 +1181,35 @@ int gpslc_y_logpdf(gpslc_ctx* c, int64_t S, const double* U, const double* X_or_
     });
 }
 
+// general (tiled, multi-launch) path of gpslc_gp_logpdf; arguments already validated
+static int gp_logpdf_general(gpslc_ctx* c, int64_t S, int32_t nF, const double* F, int32_t f_shared, const double* ls,
+                             const double* scale, const double* noise, const double* target, int32_t t_shared,
+                             double* logpdf) {
+    const size_t n = (size_t)c->n;
+    c->io.reset();
+    const double* dF = nF ? up(c, F, n * nF * (f_shared ? 1 : S)) : nullptr;
+    const double* dls = nF ? up(c, ls, (size_t)nF * S) : nullptr;
+    const double* dsc = up(c, scale, S);
+    const double* dno = up(c, noise, S);
+    const double* dtg = up(c, target, n * (t_shared ? 1 : S));
+    std::vector<double> inf(S, INFINITY);        // tyLS = inf switches the treatment term off: e_ij = exp(-0) = 1
+    const double* dty = up(c, inf.data(), S);
+    const double zero = 0.0;
+    const double* ddo = up(c, &zero, 1);
+    double* old = c->io.take<double>((size_t)S);
+    double* oq = c->io.take<double>((size_t)S);
+    PredictIO io;
+    io.S = S;
+    io.p = SampleParams{dF, dls, nullptr, dty, dsc, dno, f_shared ? 0 : (long long)n * nF};
+    io.p_shared_u = f_shared != 0;
+    io.X = nullptr; io.nU = nF; io.nX = 0;
+    io.Y = dtg; io.y_sstride = t_shared ? 0 : (long long)n;
+    io.L = 0; io.doT = ddo; io.logdet = old; io.quad = oq; io.info = c->io.take<int>((size_t)S);
+    run_predict(c, io);
+    finish_logpdf(c, S, old, oq, logpdf);
+    return first_info(c);
+}
+
 int gpslc_gp_logpdf(gpslc_ctx* c, int64_t S, int32_t nF, const double* F, int32_t f_shared, const double* ls,
                     const double* scale, const double* noise, const double* target, int32_t t_shared,
                     double* logpdf) {
@@ -1079,28 +1223,59 @@ int gpslc_gp_logpdf(gpslc_ctx* c, int64_t S, int32_t nF, const double* F, int32_
     if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
     return guarded(c, [&]() {
         const size_t n = (size_t)c->n;
-        c->io.reset();
-        const double* dF = nF ? up(c, F, n * nF * (f_shared ? 1 : S)) : nullptr;
-        const double* dls = nF ? up(c, ls, (size_t)nF * S) : nullptr;
-        const double* dsc = up(c, scale, S);
-        const double* dno = up(c, noise, S);
-        const double* dtg = up(c, target, n * (t_shared ? 1 : S));
-        std::vector<double> inf(S, INFINITY);        // tyLS = inf switches the treatment term off: e_ij = exp(-0) = 1
-        const double* dty = up(c, inf.data(), S);
-        const double zero = 0.0;
-        const double* ddo = up(c, &zero, 1);
-        double* old = c->io.take<double>((size_t)S);
-        double* oq = c->io.take<double>((size_t)S);
-        PredictIO io;
-        io.S = S;
-        io.p = SampleParams{dF, dls, nullptr, dty, dsc, dno, f_shared ? 0 : (long long)n * nF};
-        io.p_shared_u = f_shared != 0;
-        io.X = nullptr; io.nU = nF; io.nX = 0;
-        io.Y = dtg; io.y_sstride = t_shared ? 0 : (long long)n;
-        io.L = 0; io.doT = ddo; io.logdet = old; io.quad = oq; io.info = c->io.take<int>((size_t)S);
-        run_predict(c, io);
-        finish_logpdf(c, S, old, oq, logpdf);
-        return first_info(c);
+        if (!(c->flags & GPSLC_FLAG_FP32_KERNEL) && small_path_fits(c, nF) && S <= 4096) {
+            std::vector<HostNode> hn((size_t)S);
+            for (int64_t s = 0; s < S; ++s) {
+                HostNode& h = hn[s];
+                h = HostNode{};
+                h.nF = nF;
+                h.F[0] = nF ? F + (f_shared ? 0 : s * n * nF) : nullptr; h.nFpart[0] = nF; h.ls[0] = nF ? ls + s * nF : nullptr;
+                h.scale = scale[s]; h.noise = noise[s];
+                h.target = target + (t_shared ? 0 : s * n);
+            }
+            return small_nodes_logpdf(c, (int)S, hn.data(), logpdf);
+        }
+        return gp_logpdf_general(c, S, nF, F, f_shared, ls, scale, noise, target, t_shared, logpdf);
+    });
+}
+
+int gpslc_nodes_logpdf(gpslc_ctx* c, int32_t count, const gpslc_node* nodes, double* logpdf) {
+    if (!c) return -1;
+    if (count < 0) return bad_arg(c, 2, "count < 0");
+    if (count > 0 && !nodes) return bad_arg(c, 3, "nodes is NULL");
+    if (count > 0 && !logpdf) return bad_arg(c, 4, "logpdf is NULL");
+    int nF_max = 0;
+    for (int i = 0; i < count; ++i) {
+        const gpslc_node& q = nodes[i];
+        if (q.nF < 0 || q.nF > 32 || (q.nF > 0 && (!q.F || !q.ls)) || !q.target)
+            return bad_arg(c, 3, "node with nF outside 0..32 or a NULL feature / lengthscale / target pointer");
+        nF_max = std::max(nF_max, (int)q.nF);
+    }
+    if (count == 0) { c->last_info.clear(); return GPSLC_OK; }
+    return guarded(c, [&]() {
+        if (!(c->flags & GPSLC_FLAG_FP32_KERNEL) && small_path_fits(c, nF_max)) {
+            std::vector<HostNode> hn((size_t)count);
+            for (int i = 0; i < count; ++i) {
+                HostNode& h = hn[i];
+                h = HostNode{};
+                h.nF = nodes[i].nF;
+                h.F[0] = nodes[i].F; h.nFpart[0] = nodes[i].nF; h.ls[0] = nodes[i].ls;
+                h.scale = nodes[i].scale; h.noise = nodes[i].noise; h.target = nodes[i].target;
+            }
+            return small_nodes_logpdf(c, count, hn.data(), logpdf);
+        }
+        // larger n: one pass of the general tiled path per node (their feature counts differ)
+        int first = 0;
+        std::vector<int32_t> infos((size_t)count, 0);
+        for (int i = 0; i < count; ++i) {
+            const gpslc_node& q = nodes[i];
+            const int st = gp_logpdf_general(c, 1, q.nF, q.F, 1, q.ls, &q.scale, &q.noise, q.target, 1, logpdf + i);
+            if (st < 0) return st;
+            infos[i] = st;
+            if (st > 0 && first == 0) first = st;
+        }
+        c->last_info = infos;
+        return first;
     });
 }
 

@@ -220,6 +220,23 @@ void launch_ld_build(const LdBuildArgs& a, hipStream_t st);
 struct RectGatherArgs { TRef R; int n, nt; double* out; double diag_add; };   // -> column-major n x n
 void launch_rect_gather(const RectGatherArgs& a, hipStream_t st);
 
+// single-launch node score for small n (k_small.hip): one workgroup per node, matrix resident in LDS
+struct SmallNode {
+    const double* F;        // n x nF, column-major
+    const double* ls;       // nF
+    const double* target;   // n
+    double scale, noise;
+    int nF;
+    int pad_;
+};
+struct SmallArgs {
+    const SmallNode* nodes;
+    int n, NB;              // NB = ceil(n / 16) block rows
+    double* out;            // [count][4]: logdet, quad, info (1-based failing pivot, 0 = ok), reserved
+};
+size_t small_gp_lds_bytes(int n, int nF);
+void launch_small_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st);
+
 // summarizeEstimates (src/driver.jl:129-149): per-row mean and two type-7 quantiles of an n x m sample matrix
 struct SummArgs {
     const double* x; long long rs, cs;   // sample (i, j) at x[i*rs + j*cs]

@@ -189,9 +189,7 @@ class _RealTChain:
         if binary:                        # :logitT from its prior, the :T => i => :T nodes are constrained
             self.logitT = np.linalg.cholesky(self._t_cov()) @ rng.standard_normal(self.n)
         self.s_u = self.score_u()
-        self.s_x = self.score_x()            # array over k (empty without covariates)
-        self.s_t = self.score_t()
-        self.s_y = self.score_y()
+        self.s_x, self.s_t, self.s_y = self.score_xty()     # s_x: array over k (empty without covariates)
         self.s_b = self.score_b() if binary else 0.0
 
     # ---- binary treatments: :logitT ~ mvnormal(0, logitTCov), :T => i => :T ~ bernoulli(expit(logitT_i))
@@ -281,6 +279,30 @@ class _RealTChain:
         ls = np.concatenate(([v["uyLS"]] if self.nU else []) + ([v["xyLS"]] if self.nX else []) + [[v["tyLS"]]])
         return float(api.gpLogpdf(np.column_stack(cols), ls, v["yScale"], v["yNoise"], self.Y, ctx=self.ctx)[0])
 
+    def score_xty(self, v=None, U=None):
+        """Every node a move of U touches — the nX `:X => k => :X` nodes, `:T` / `:logitT` and `:Y` — in ONE fused
+        call (gpslc_nodes_logpdf): what a Gen `update` of `:U => k => :U` re-scores (src/inference.jl:48-54)."""
+        v = v or self.v
+        nodes = []
+        Um = self._umodel(U) if self.nU else None
+        nx = self.nX if (self.nX and self.nU) else 0
+        if nx:
+            ls = self._uxls_model(v)
+            for k in range(self.nX):
+                nodes.append((Um, ls[k], v["xScale"][k], v["xNoise"][k], self.X[:, k]))
+        Ft, lst = self._t_features(U, v)
+        target = self.logitT if self.binary else self.T
+        has_t = Ft.shape[1] > 0
+        if has_t:
+            nodes.append((Ft, lst, v["tScale"], v["tNoise"], target))
+        cols = ([Um] if self.nU else []) + ([self.X] if self.nX else []) + [self.T]
+        lsy = np.concatenate(([v["uyLS"]] if self.nU else []) + ([v["xyLS"]] if self.nX else []) + [[v["tyLS"]]])
+        nodes.append((np.column_stack(cols), lsy, v["yScale"], v["yNoise"], self.Y))
+        out = api.nodesLogpdf(nodes, self.ctx)
+        sx = out[:nx].copy()
+        st = float(out[nx]) if has_t else float(-0.5 * (target @ target) - 0.5 * self.n * math.log(2.0 * math.pi))
+        return sx, st, float(out[-1])
+
     # which node an address touches
     TOUCH = {"uNoise": "u", "tNoise": "t", "yNoise": "y", "tyLS": "y", "tScale": "t", "yScale": "y",
              "utLS": "t", "uyLS": "y", "uxLS": "x", "xNoise": "x", "xScale": "x", "xtLS": "t", "xyLS": "y"}
@@ -348,7 +370,7 @@ class _RealTChain:
             U2 = list(self.U)
             U2[k] = prop
             try:
-                sx, st, sy = self.score_x(U=U2), self.score_t(U=U2), self.score_y(U=U2)
+                sx, st, sy = self.score_xty(U=U2)
             except api.PosDefException:
                 sx, st, sy = np.zeros(0), -math.inf, -math.inf
             if float(np.sum(sx)) + st + sy > log_y:

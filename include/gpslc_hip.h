@@ -116,6 +116,24 @@ int gpslc_gp_logpdf(gpslc_ctx* ctx, int64_t S, int32_t nF, const double* F, int3
                     const double* ls, const double* scale, const double* noise, const double* target,
                     int32_t t_shared, double* logpdf /* S */);
 
+/* The fused whole-model score: `count` independent Gaussian-process nodes, each with its OWN feature block, in one
+ * call — what one Gen `update` re-scores (src/model.jl:11-131): the nX `:X => k => :X` nodes, `:T` / `:logitT` and
+ * `:Y` (F = [U | X | T], ls = [uyLS ; xyLS ; tyLS]) of a proposal, or the nodes of several proposals at once.
+ * logpdf[i] = log N(target_i; 0, scale_i * exp.(rbfKernelLog(F_i, F_i, ls_i)) + noise_i * I); host pointers.
+ * While the n x n matrix fits one CU's LDS (n <= 160 for any nF <= 32, up to n = 176 for nF <= 17) ALL nodes are
+ * scored by ONE kernel launch, one workgroup per node (Gram build, Cholesky, forward solve and reductions never
+ * leave the CU); gpslc_gp_logpdf and gpslc_y_logpdf take the same path at those sizes.  Larger n: the general
+ * tiled path, node by node.  Return value and gpslc_last_info (count entries) as for gpslc_gp_logpdf. */
+typedef struct gpslc_node {
+    int32_t nF;            /* feature columns, 0..32 */
+    int32_t reserved;
+    const double* F;       /* n x nF, column-major */
+    const double* ls;      /* nF */
+    double scale, noise;
+    const double* target;  /* n */
+} gpslc_node;
+int gpslc_nodes_logpdf(gpslc_ctx* ctx, int32_t count, const gpslc_node* nodes, double* logpdf /* count */);
+
 /* log N(x_s; 0, covscale_s * cov) for S vectors and one dense n x n covariance: the :U => u => :U nodes
  * (generateUfromSigmaU, src/model_likelihood.jl:4-10 with uCov = SigmaU * uNoise; generateU,
  * src/model_prior.jl:27-30).  A non-NULL cov is factorised and the factor cached in the ctx (SigmaU is

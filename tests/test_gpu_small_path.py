@@ -1,0 +1,97 @@
+"""The single-launch node score (k_small.hip, gpslc_nodes_logpdf): Gram build, Cholesky, forward solve and the
+reductions of one Gaussian-process node inside one workgroup, many heterogeneous nodes per launch — the
+reference's own problem sizes (NEEC n = 150; src/model_likelihood.jl:4-120, src/inference.jl:21-56).
+Oracle: Gen's mvnormal score restated (orc.mvnormal_logpdf of the restated covariance)."""
+import numpy as np
+import pytest
+
+import gpslc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(F, ls, scale, noise, target):
+    n = len(target)
+    if F is None:
+        cov = scale * np.ones((n, n)) + noise * np.eye(n)
+    else:
+        cov = orc.process_cov(orc.rbf_kernel_log(F, F, np.asarray(ls, dtype=float)), scale, noise)
+    return orc.mvnormal_logpdf(np.asarray(target, dtype=float), cov)
+
+
+@pytest.mark.parametrize("n", [1, 5, 15, 16, 17, 31, 33, 100, 150, 160, 176, 177, 200])
+def test_heterogeneous_nodes_one_call(gp, n):
+    """Nodes with different feature counts in one call; n = 176 is the last size that fits the LDS-resident path with
+    these feature counts, 177 and 200 take the general tiled path node by node: same answers."""
+    rng = np.random.default_rng(1000 + n)
+    ctx = gp.Context(n, 0, 0)
+    nodes = []
+    for nF in (0, 1, 3, 8, 17):
+        F = None if nF == 0 else rng.standard_normal((n, nF))
+        ls = None if nF == 0 else rng.uniform(0.6, 2.0, nF)
+        nodes.append((F, ls, rng.uniform(0.5, 2.0), rng.uniform(0.3, 1.5), rng.standard_normal(n)))
+    out = gp.nodesLogpdf(nodes, ctx)
+    ref = np.array([_ref(*q) for q in nodes])
+    assert np.allclose(out, ref, rtol=1e-11, atol=1e-9), (out, ref)
+    assert not ctx.last_info(len(nodes)).any()
+    # the per-node entry point gives the same numbers as the fused call
+    one = gp.gpLogpdf(nodes[3][0], nodes[3][1], nodes[3][2], nodes[3][3], nodes[3][4], ctx=ctx)
+    assert abs(one[0] - out[3]) <= 1e-12 * abs(out[3])
+
+
+def test_wide_feature_block_limits(gp):
+    """nF = 32 fits up to n = 160; n = 161..176 with nF = 32 must fall back to the general path, silently."""
+    rng = np.random.default_rng(5)
+    for n in (160, 170):
+        F = rng.standard_normal((n, 32))
+        ls = rng.uniform(2.0, 4.0, 32)
+        y = rng.standard_normal(n)
+        out = gp.nodesLogpdf([(F, ls, 1.1, 0.6, y)], gp.Context(n, 0, 0))
+        assert abs(out[0] - _ref(F, ls, 1.1, 0.6, y)) <= 1e-11 * abs(out[0])
+
+
+def test_y_node_with_treatment_column_small_n(gp):
+    """gpslc_y_logpdf at n = 150 (the NEEC size) runs the single-launch path with T as a feature column; S parameter
+    sets = S workgroups of one launch; the X and Y overrides are honoured."""
+    import cases
+    c = cases.make_case(150, "UX", False, S=5, seed=33)
+    g = cases.gpslc_object(gp, c)
+    lp = gp.yLogpdf(g)
+    for s, p in enumerate(cases.samples_of(c)):
+        ref = orc.y_logpdf(p.uyLS, p.xyLS, p.tyLS, p.yScale, p.yNoise, p.U, c["X"], c["T"], c["Y"])
+        assert abs(lp[s] - ref) <= 1e-11 * abs(ref)
+    X2 = c["X"] + 0.1
+    y2 = c["Y"][::-1].copy()
+    lp2 = gp.yLogpdf(g, X_override=X2, Y_override=y2)
+    p = cases.samples_of(c)[2]
+    ref = orc.y_logpdf(p.uyLS, p.xyLS, p.tyLS, p.yScale, p.yNoise, p.U, X2, c["T"], y2)
+    assert abs(lp2[2] - ref) <= 1e-11 * abs(ref)
+
+
+@pytest.mark.parametrize("j", [0, 1, 15, 16, 17, 47, 48, 100, 149])
+def test_failing_pivot_small_path(gp, j):
+    """Not positive definite -> LAPACK-style info (1-based pivot), across 16 x 16 block boundaries of the in-LDS
+    factorisation: duplicate instances + zero noise make the Gram matrix exactly singular at the second copy."""
+    n = 150
+    rng = np.random.default_rng(j)
+    F = rng.standard_normal((n, 2))
+    if j > 0:
+        F[j] = F[j - 1]                   # row j duplicates row j-1: pivot j is 0 (or rounding-negative)
+    ctx = gp.Context(n, 0, 0)
+    noise = 0.0 if j > 0 else -2.0        # j = 0: negative diagonal from the start
+    with pytest.raises(gp.PosDefException) as ei:
+        gp.nodesLogpdf([(F, [1.0, 1.5], 1.0, noise, rng.standard_normal(n))], ctx)
+    assert ei.value.info == j + 1
+    assert ctx.last_info(1)[0] == j + 1
+
+
+def test_many_nodes_one_launch(gp):
+    """A few hundred nodes (e.g. many proposals scored at once) = a few hundred workgroups of one launch."""
+    n, cnt = 96, 300
+    rng = np.random.default_rng(77)
+    F = rng.standard_normal((n, 3))
+    y = rng.standard_normal(n)
+    nodes = [(F, rng.uniform(0.5, 2.0, 3), rng.uniform(0.5, 2.0), rng.uniform(0.3, 1.0), y) for _ in range(cnt)]
+    out = gp.nodesLogpdf(nodes, gp.Context(n, 0, 0))
+    for i in (0, 7, 150, 299):
+        assert abs(out[i] - _ref(*nodes[i])) <= 1e-11 * abs(out[i])

@@ -1,25 +1,38 @@
 #!/usr/bin/env python3
-"""Latency of one model-node score at the reference's own problem sizes (what an MH / slice step waits for)."""
+"""Latency of model-node scores at the reference's own problem sizes (what an MH / slice step waits for), and the
+wall time of the NEEC gpslc() chain (BASELINE config 0)."""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import causalgpslc_jl_amd as gp   # noqa: E402
 
-for n, F in ((150, 2), (272, 8), (1000, 8)):
+for n, F in ((150, 2), (150, 8), (160, 3), (272, 8), (1000, 8)):
     rng = np.random.default_rng(n)
     Fm = rng.standard_normal((n, F))
     ls = 1.0 + rng.random(F)
     y = rng.standard_normal(n)
     ctx = gp.Context(n, 0, 0)
-    ctx.set_data(None, np.zeros(n), np.zeros(n))
     gp.gpLogpdf(Fm, ls, 1.3, 0.4, y, ctx=ctx)
     reps = 300
     t0 = time.perf_counter()
     for _ in range(reps):
         gp.gpLogpdf(Fm, ls, 1.3, 0.4, y, ctx=ctx)
     dt = (time.perf_counter() - t0) / reps
-    print(f"n={n} F={F}: gpLogpdf {dt * 1e6:.0f} us per call")
+    nodes = [(Fm, ls, 1.3, 0.4, y)] * 3
+    gp.nodesLogpdf(nodes, ctx)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gp.nodesLogpdf(nodes, ctx)
+    dt3 = (time.perf_counter() - t0) / reps
+    print(f"n={n} F={F}: gpLogpdf {dt * 1e6:.0f} us per score; fused 3-node call {dt3 * 1e6:.0f} us", flush=True)
+
+neec = os.path.join(ROOT, "tests", "golden", "neec", "NEEC_sampled.csv")
+gp.gpslc(neec, seed=1)
+t0 = time.perf_counter()
+g = gp.gpslc(neec, seed=1234)
+print(f"gpslc(NEEC_sampled.csv), default hyper-parameters: {time.perf_counter() - t0:.2f} s", flush=True)
