@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--binary-t", action="store_true", help="Bernoulli(0.5) treatments (BASELINE config 5 shape)")
     ap.add_argument("--fp32-kernel", action="store_true", help="mixed precision: RBF evaluation in fp32 (config 5)")
+    ap.add_argument("--diag-lib", action="store_true",
+                    help="measurement only: load libgpslc_hip_diag.so (make diag), the build in which the GPSLC_* "
+                         "environment switches exist; never used for reported numbers")
     return ap.parse_args()
 
 
@@ -243,6 +246,8 @@ def main():
 
     import causalgpslc_jl_amd as gp
     from causalgpslc_jl_amd import synth
+    if a.diag_lib:
+        gp._lib.LIB_PATH = gp._lib.LIB_PATH.replace("libgpslc_hip.so", "libgpslc_hip_diag.so")
 
     n, D, K, L = a.n, a.d, a.nu, a.levels
     Sr = a.samples_per_step
@@ -327,7 +332,7 @@ def main():
             "value": val, "unit": "posterior samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if not a.fp32_kernel else "f64 factorisation, f32 kernel build",
-            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo — not a result)" if rehearsal else ""),
+            "data": "synthetic" + (" (MEASUREMENT BUILD libgpslc_hip_diag.so — not a result)" if a.diag_lib else "") + (" (REHEARSAL: all ranks on one GPU, gloo — not a result)" if rehearsal else ""),
             "config": {"workload": f"Synthetic N={n} D={D} nU={K}, unit A (Gram build + potrf + alpha + MeanITE + "
                                    f"SATE mean/var), L={L} level(s), {Sr} posterior samples per GPU per step"
                                    + (", binary treatment" if a.binary_t else ""),

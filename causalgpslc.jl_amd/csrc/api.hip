@@ -247,6 +247,8 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st, int prof_base = 0) {
     GemmArgs g = g0;
     g.diag_skip = 0;
     g.dbg = nullptr;
+    static const int nt_c = diag_env("GPSLC_NT_C", 0);
+    g.nt_c = (nt_c && g.shape == 0) ? 1 : 0;      // trailing updates only
     static const int use_queue = diag_env("GPSLC_GEMM_QUEUE", 1);
     g.queue = nullptr;
     if (use_queue)
@@ -787,11 +789,11 @@ int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* l
     size_t doubles = 0;
     int nF_max = 0;
     for (int i = 0; i < count; ++i) {
-        doubles += n * nodes[i].nF + nodes[i].nF + n;
+        doubles += n * nodes[i].nF + n;
         nF_max = std::max(nF_max, nodes[i].nF);
     }
     const size_t off_out = ((size_t)count * sizeof(SmallNode) + 63) & ~size_t(63);
-    const size_t off_data = off_out + (size_t)count * 4 * sizeof(double);
+    const size_t off_data = off_out + (size_t)count * 12 * sizeof(double);     // 4 results + 8 stamp words per node
     pin_reserve(c, off_data + doubles * sizeof(double));
     void* dbase = nullptr;
     HC(hipHostGetDevicePointer(&dbase, c->pin, 0));
@@ -801,30 +803,47 @@ int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* l
     double* hd = reinterpret_cast<double*>(c->pin + off_data);
     double* dd = reinterpret_cast<double*>(dev + off_data);
     size_t o = 0;
+    // features are staged already divided by their lengthscale: x * (1 / l), the arithmetic of the general path
+    auto put_scaled = [&](const double* col, double l) {
+        const double il = 1.0 / l;
+        for (size_t r = 0; r < n; ++r) hd[o + r] = col[r] * il;
+        o += n;
+    };
     for (int i = 0; i < count; ++i) {
         const HostNode& h = nodes[i];
         SmallNode& sn = hn[i];
         sn.nF = h.nF; sn.pad_ = 0; sn.scale = h.scale; sn.noise = h.noise;
-        sn.F = dd + o;
+        sn.Fs = dd + o;
         for (int g = 0; g < 2; ++g)
-            if (h.nFpart[g] > 0) { memcpy(hd + o, h.F[g], n * h.nFpart[g] * sizeof(double)); o += n * h.nFpart[g]; }
-        if (h.col) { memcpy(hd + o, h.col, n * sizeof(double)); o += n; }
-        sn.ls = dd + o;
-        for (int g = 0; g < 2; ++g)
-            if (h.nFpart[g] > 0) { memcpy(hd + o, h.ls[g], h.nFpart[g] * sizeof(double)); o += h.nFpart[g]; }
-        if (h.col) hd[o++] = h.ls_col;
+            for (int f = 0; f < h.nFpart[g]; ++f) put_scaled(h.F[g] + (size_t)f * n, h.ls[g][f]);
+        if (h.col) put_scaled(h.col, h.ls_col);
         sn.target = dd + o;
         memcpy(hd + o, h.target, n * sizeof(double));
         o += n;
     }
     SmallArgs a{};
     a.nodes = reinterpret_cast<const SmallNode*>(dev);
+    for (int i = 0; i < std::min(count, SMALL_INLINE_NODES); ++i) a.inl[i] = hn[i];
     a.n = (int)n; a.NB = (int)((n + 15) / 16);
     a.out = reinterpret_cast<double*>(dev + off_out);
+    a.stamps = nullptr;
+#ifdef GPSLC_DIAG
+    static const int want_stamps = diag_env("GPSLC_SMALL_STAMPS", 0);
+    if (want_stamps) a.stamps = a.out + 4 * (size_t)count;
+#endif
     hipStream_t st = c->streams[0];
     launch_small_gp(a, count, nF_max, st);
     HC(hipGetLastError());
     HC(hipStreamSynchronize(st));
+#ifdef GPSLC_DIAG
+    if (want_stamps) {
+        static int printed = 0;
+        const double* sp = hout + 4 * (size_t)count;
+        if (printed++ < want_stamps)
+            fprintf(stderr, "small_gp stamps (shader clocks): inputs %.0f gram %.0f factor+panel %.0f update %.0f total %.0f\n",
+                    sp[0], sp[1], sp[2], sp[3], sp[5]);
+    }
+#endif
     const double l2pi = 1.8378770664093454835606594728112;
     int first = 0;
     c->last_info.resize((size_t)count);

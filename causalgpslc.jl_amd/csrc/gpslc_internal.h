@@ -97,6 +97,8 @@ struct GemmArgs {
     int* queue;       // optional: 16 zero-initialised ints (per-XCD ticket counters [0..8), exit counters [8..16))
                       // owned by the launching stream; the kernel leaves them zeroed again.  null = static stride
     const unsigned short* order;  // optional (ii, jj) pairs: output-tile visiting order (L2-blocked), or null
+    int nt_c;                     // C tiles are loaded / stored with the non-temporal hint (streamed once per launch:
+                                  // they should not displace the operand slabs the co-resident workgroups share in L2)
     int diag_skip;                // DIAGNOSTIC ONLY (GPSLC_GEMM_DIAG): 1 = skip in-loop global loads, 2 = also LDS writes
     unsigned long long* dbg;      // diagnostic builds only: per-workgroup s_memtime stamps, or null
 };
@@ -222,17 +224,19 @@ void launch_rect_gather(const RectGatherArgs& a, hipStream_t st);
 
 // single-launch node score for small n (k_small.hip): one workgroup per node, matrix resident in LDS
 struct SmallNode {
-    const double* F;        // n x nF, column-major
-    const double* ls;       // nF
+    const double* Fs;       // n x nF, column-major, ALREADY divided by the lengthscales: Fs[i, f] = F[i, f] * (1 / ls[f])
     const double* target;   // n
     double scale, noise;
     int nF;
     int pad_;
 };
+#define SMALL_INLINE_NODES 4
 struct SmallArgs {
-    const SmallNode* nodes;
+    const SmallNode* nodes; // descriptors of the nodes >= SMALL_INLINE_NODES (device-visible memory)
+    SmallNode inl[SMALL_INLINE_NODES];   // the first nodes travel in the kernel arguments: no dependent host-memory read
     int n, NB;              // NB = ceil(n / 16) block rows
     double* out;            // [count][4]: logdet, quad, info (1-based failing pivot, 0 = ok), reserved
+    double* stamps;         // measurement build only: [count][8] phase timings, else null
 };
 size_t small_gp_lds_bytes(int n, int nF);
 void launch_small_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st);

@@ -9,17 +9,21 @@
 // the general path spends ~15 dependent launches (20-60 us each) on the same score, and an `mh` / slice step of
 // the Markov chain waits for exactly that.
 //
-// CDNA4 mapping
+// CDNA4 mapping (8 wave64 per workgroup, one workgroup per CU)
 //   * the lower triangle lives in LDS as packed 16 x 16 fp64 blocks (2 KiB each, column-major): n = 150 -> 55 blocks
 //     = 110 KiB of the CU's 160 KiB; the scaled features (n x nF) and the right-hand side sit beside it;
-//   * right-looking blocked Cholesky, block size 16 = one f64 MFMA tile:
-//       potf2   wave 0, in registers: lane i holds row i, the pivot row travels by v_readlane (no LDS, no barrier
-//               inside the 16 columns); also produces W = inv(L_pp)
-//       panel   X_i = A_ip W^T (4 MFMAs per block) on all waves, z_p = y_p W^T
-//       update  A_ij -= X_i X_j^T (4 MFMAs per block), y_j -= z_p X_j^T
-//     with ONE level of look-ahead: the blocks of column p+1 are updated first, then wave 0 factors block
-//     (p+1, p+1) while waves 1-3 finish the rest of the trailing update — the serial potf2 chain (the critical
-//     path: 16 dependent pivots per block) hides behind the MFMA work of the other waves;
+//   * right-looking blocked Cholesky, block size 16 = one f64 MFMA tile.  Per block column p:
+//       factor + panel in ONE register-resident pass: the Cholesky of the 16 x 16 diagonal block is a sequence of
+//               column operations (scale column c by 1/sqrt(pivot), subtract multiples of it from the columns right
+//               of it); applied to the rows BELOW the block they turn A_ip into X_i = A_ip L_pp^-T, and applied to
+//               the right-hand side row they turn y_p into z_p.  Every wave keeps its own copy of the diagonal
+//               block's 16 rows in lanes 0-15 (row i in lane i, the pivot row travels by v_readlane) and 48 of the
+//               rows below in lanes 16-63: the panel solve costs no instruction and no barrier of its own, and no
+//               inverse of L_pp is ever formed;
+//       update  A_ij -= X_i X_j^T (4 MFMAs per block) dealt to the 8 waves, y_j -= z_p X_j^T on the VALU;
+//     two barriers per block column.  The critical path is the chain of 16 dependent pivots per block: reciprocal
+//     square root by v_rsq_f64 + one third-order correction, the column scaling uses it directly (the square root
+//     itself is only needed for the diagonal entry and is finished off the chain);
 //   * inputs are read straight from the pinned host staging buffer (a few KB, coalesced, once) and the three result
 //     words are written back to it: a score costs one kernel launch and one stream synchronisation.
 #include "gpslc_internal.h"
@@ -28,6 +32,8 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define SB 16
+#define SM_THREADS 512
+#define SM_WAVES (SM_THREADS / 64)
 #define SBLK(i, j) (P + ((((i) * ((i) + 1)) / 2 + (j)) << 8))
 
 __device__ __forceinline__ double sm_readlane(double x, int lane) {
@@ -40,48 +46,35 @@ __device__ __forceinline__ double sm_frag(const double* blk, int kk, int lane) {
     return blk[(4 * kk + (lane >> 4)) * SB + (lane & 15)];
 }
 
-// 16 x 16 Cholesky of block D in registers (every 16-lane group mirrors rows 0..15) + its inverse into Wc
-// (Wc[c*16 + r] = inv(L)[r][c]); returns sum of log(L_cc); bad = 1-based first non-positive pivot (0 = ok)
-__device__ __forceinline__ double sm_potf2(double* D, double* Wc, int lane, int base, int& bad) {
-    const int li = lane & 15;
-    double r[SB], isd[SB];
-    double ld = 0.0;
-#pragma unroll
-    for (int c = 0; c < SB; ++c) r[c] = D[c * SB + li];
+// The column operations of the 16 x 16 Cholesky applied to this lane's row r[0..15] of block column p.
+// Lanes 0..15 of the wave hold rows 0..15 of the diagonal block itself (row i in lane i): their lower triangle ends up
+// holding L_pp — except the diagonal entry, which is left as pivot * pivot^-1/2 (uncorrected) inside the loop and is
+// returned, properly rounded, through `lcc` (lane c: L_cc), and the upper triangle, which holds rounding residue nobody
+// reads.  Every other lane holds a row below the block (or the right-hand side) and ends up holding that row of
+// A_ip L_pp^-T.  Nothing but the pivot chain sits in the loop: readlane -> rsq -> 4 dependent flops -> scale -> first
+// update -> next readlane.  bad = 1-based first non-positive pivot (0 = ok), wave-uniform.
+__device__ __forceinline__ void sm_factor_rows(double (&r)[SB], int li, int base, int& bad, double& lcc) {
+    double dsave = 1.0, ysave = 1.0;          // pivot and its reciprocal square root of THIS lane's column (lane c: column c)
 #pragma unroll
     for (int c = 0; c < SB; ++c) {
-        const double d = sm_readlane(r[c], c);
+        const double d = sm_readlane(r[c], c);                 // pivot: row c of the diagonal block lives in lane c
         if (!(d > 0.0) && bad == 0) bad = base + c + 1;
-        double y = __builtin_amdgcn_rsq(d);
-        y = y * (1.5 - 0.5 * d * y * y);
-        y = y * (1.5 - 0.5 * d * y * y);
-        double s = d * y;
-        s = fma(fma(-s, s, d), 0.5 * y, s);       // sqrt(d), Newton-corrected
-        y = fma(fma(-s, y, 1.0), y, y);           // 1/s
-        isd[c] = y;
-        ld += log(s);
-        r[c] = (li > c) ? r[c] * y : (li == c ? s : 0.0);
+        // y = d^-1/2: hardware estimate (~2^-23) + one third-order step (error^3 ~ 2^-69)
+        const double y0 = __builtin_amdgcn_rsq(d);
+        const double e = fma(-d * y0, y0, 1.0);
+        const double y = fma(y0 * e, fma(e, 0.375, 0.5), y0);
+        r[c] *= y;
 #pragma unroll
         for (int j = c + 1; j < SB; ++j) {
-            const double ljc = sm_readlane(r[c], j);
+            const double ljc = sm_readlane(r[c], j);           // L[j][c], row j of the diagonal block = lane j
             r[j] = fma(-r[c], ljc, r[j]);
         }
+        if (li == c) { dsave = d; ysave = y; }
     }
-    double w[SB];      // lane j owns column j of W = inv(L)
-#pragma unroll
-    for (int i = 0; i < SB; ++i) {
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < i; ++m) acc = fma(sm_readlane(r[m], i), w[m], acc);
-        w[i] = (i == li) ? isd[i] : ((i > li) ? -acc * isd[i] : 0.0);
-    }
-    if (lane < SB) {
-#pragma unroll
-        for (int c = 0; c < SB; ++c) D[c * SB + li] = r[c];
-#pragma unroll
-        for (int i = 0; i < SB; ++i) Wc[li * SB + i] = w[i];
-    }
-    return ld;
+    // L_cc = sqrt(pivot_c): d*y with one Newton correction, once per lane, off the chain
+    double sq = dsave * ysave;
+    sq = fma(fma(-sq, sq, dsave), 0.5 * ysave, sq);
+    lcc = sq;
 }
 
 // A_ij -= X_i X_j^T for one 16 x 16 block (X_i = block (i, p), X_j = block (j, p))
@@ -97,126 +90,184 @@ __device__ __forceinline__ void sm_update(double* Aij, const double* Xi, const d
     for (int v = 0; v < 4; ++v) Aij[(lg + 4 * v) * SB + li] = acc[v];
 }
 
-__global__ __launch_bounds__(256) void small_gp_logpdf_kernel(SmallArgs a) {
+// the same for two blocks at once (independent accumulators)
+__device__ __forceinline__ void sm_update2(double* A0, const double* Xi0, const double* Xj0, double* A1, const double* Xi1,
+                                           const double* Xj1, int lane) {
+    const int li = lane & 15, lg = lane >> 4;
+    d4 acc0, acc1;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { acc0[v] = A0[(lg + 4 * v) * SB + li]; acc1[v] = A1[(lg + 4 * v) * SB + li]; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sm_frag(Xj0, kk, lane), sm_frag(Xi0, kk, lane), acc0, 0, 0, 1);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sm_frag(Xj1, kk, lane), sm_frag(Xi1, kk, lane), acc1, 0, 0, 1);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { A0[(lg + 4 * v) * SB + li] = acc0[v]; A1[(lg + 4 * v) * SB + li] = acc1[v]; }
+}
+
+// one Gram entry: scale * exp(-sum_f (x_f/l_f - x'_f/l_f)^2) (+ noise on the diagonal); identity on the padding
+__device__ __forceinline__ double sm_gram_entry(const double* fs, int NP, int nF, int n, int i, int j, double scale,
+                                                double noise) {
+    if (i >= n || j >= n) return (i == j) ? 1.0 : 0.0;
+    double lux = 0.0;
+    for (int f = 0; f < nF; ++f) {
+        const double d = fs[f * NP + i] - fs[f * NP + j];
+        lux = fma(d, d, lux);
+    }
+    const double v = scale * gp_exp_neg(-lux);
+    return (i == j) ? v + noise : v;
+}
+
+__global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) double P[];
-    const SmallNode nd = a.nodes[blockIdx.x];
+    const unsigned long long tstart = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+    const SmallNode nd = blockIdx.x < SMALL_INLINE_NODES ? a.inl[blockIdx.x] : a.nodes[blockIdx.x];
     const int n = a.n, NB = a.NB, NP = NB * SB;
     const int NBLK = NB * (NB + 1) / 2;
-    double* Wcur = P + NBLK * 256;
-    double* yv = Wcur + 256;          // right-hand side, updated in place block by block
+    double* yv = P + NBLK * 256;      // right-hand side, updated in place block by block
     double* zv = yv + NP;             // z = L^-1 target
-    double* fs = zv + NP;             // scaled features, fs[f*NP + i] = F[i, f] / ls[f]
+    double* ldv = zv + NP;            // diag(L), for the log-determinant
+    double* fs = ldv + NP;            // scaled features, fs[f*NP + i] = F[i, f] * (1 / ls[f]) (scaled by the host)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lg = lane >> 4;
-    const int er = tid & 15, ec = tid >> 4;
+    const int li = lane & 15;
 
-    for (int idx = tid; idx < nd.nF * NP; idx += 256) {
+    for (int idx = tid; idx < nd.nF * NP; idx += SM_THREADS) {
         const int f = idx / NP, i = idx - f * NP;
-        fs[idx] = (i < n) ? nd.F[(long long)f * n + i] * (1.0 / nd.ls[f]) : 0.0;
+        fs[idx] = (i < n) ? nd.Fs[(long long)f * n + i] : 0.0;
     }
-    for (int i = tid; i < NP; i += 256) yv[i] = (i < n) ? nd.target[i] : 0.0;
+    for (int i = tid; i < NP; i += SM_THREADS) yv[i] = (i < n) ? nd.target[i] : 0.0;
     __syncthreads();
+    const unsigned long long t0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
 
-    // ---- Gram build into the packed blocks: scale * exp(-sum_f (x_f/l_f - x'_f/l_f)^2) + noise on the diagonal
-    // (src/kernel.jl:13-32, 53-59); identity on the padding rows
-    for (int bi = 0; bi < NB; ++bi)
-        for (int bj = 0; bj <= bi; ++bj) {
-            const int i = SB * bi + er, j = SB * bj + ec;
-            double v;
-            if (i < n && j < n) {
-                double lux = 0.0;
-                for (int f = 0; f < nd.nF; ++f) {
-                    const double d = fs[f * NP + i] - fs[f * NP + j];
-                    lux = fma(d, d, lux);
-                }
-                v = nd.scale * gp_exp_neg(-lux);
-                if (i == j) v += nd.noise;
-            } else {
-                v = (i == j) ? 1.0 : 0.0;
+    // ---- Gram build into the packed blocks (src/kernel.jl:13-32, 53-59): one block per wave and iteration, four
+    // independent entries per lane (the exp chains of a wave would otherwise run back to back)
+    {
+        int bi = 0, bj = 0;                              // block `wave` of the row-major lower-triangle enumeration
+        for (int t = 0; t < wave; ++t) { if (++bj > bi) { ++bi; bj = 0; } }
+        for (int blk = wave; blk < NBLK; blk += SM_WAVES) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = lane + 64 * u;
+                v[u] = sm_gram_entry(fs, NP, nd.nF, n, SB * bi + (w & 15), SB * bj + (w >> 4), nd.scale, nd.noise);
             }
-            SBLK(bi, bj)[tid] = v;
+            double* B = P + (blk << 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) B[lane + 64 * u] = v[u];
+            for (int t = 0; t < SM_WAVES; ++t) { if (++bj > bi) { ++bi; bj = 0; } }
         }
+    }
     int bad = 0;
-    double logdet = 0.0;
+    unsigned long long t_fac = 0, t_upd = 0, tq = 0;    // measurement build only
     __syncthreads();
-    if (wave == 0) logdet += sm_potf2(SBLK(0, 0), Wcur, lane, 0, bad);
-    __syncthreads();
+    if (a.stamps) tq = __builtin_amdgcn_s_memtime();
+    const unsigned long long t1 = tq;
 
     for (int p = 0; p < NB; ++p) {
-        // ---- panel: X_i = A_ip W_pp^T for the blocks below the diagonal; z_p = y_p W_pp^T
-        for (int i = p + 1 + wave; i < NB; i += 4) {
-            double* Aip = SBLK(i, p);
-            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        // ---- factor + panel: the column operations of chol(A_pp) on the diagonal block's rows (lanes 0-15 of every
+        // wave that carries rows) and on the rows below / the right-hand side (lanes 16-63: 48 rows per wave)
+        {
+            const int rows = NP - SB * (p + 1);              // matrix rows below the block; row index `rows` = y
+            if (wave * 48 <= rows) {                         // wave-uniform: this wave has rows to carry
+                const bool is_diag = lane < SB;
+                const int q = wave * 48 + (lane - SB);       // this lane's row below the block (lanes >= 16)
+                double r[SB];
+                double* dst = nullptr;                       // where this lane's row lives (null: nothing to carry)
+                if (is_diag) dst = SBLK(p, p) + li;
+                else if (q < rows) { const int gr = SB * (p + 1) + q; dst = SBLK(gr >> 4, p) + (gr & 15); }
+                const bool is_y = !is_diag && q == rows;
+                if (dst) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sm_frag(Wcur, kk, lane), sm_frag(Aip, kk, lane), acc, 0, 0, 0);
+                    for (int c = 0; c < SB; ++c) r[c] = dst[c * SB];
+                } else if (is_y) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) Aip[(lg + 4 * v) * SB + li] = acc[v];
-        }
-        if (wave == 3 && lane < SB) {      // z_p[c'] = sum_{c <= c'} y_p[c] W[c'][c]
-            double acc = 0.0;
-            for (int c = 0; c <= lane; ++c) acc = fma(yv[SB * p + c], Wcur[c * SB + lane], acc);
-            zv[SB * p + lane] = acc;
-        }
-        __syncthreads();
-        if (p + 1 >= NB) break;
-        // ---- trailing update, column p+1 first (look-ahead): blocks (i, p+1), i >= p+1, and y_{p+1}
-        for (int i = p + 1 + wave; i < NB; i += 4) sm_update(SBLK(i, p + 1), SBLK(i, p), SBLK(p + 1, p), lane);
-        if (wave == 3 && lane < SB) {      // y_{p+1}[c] -= sum_k z_p[k] X_{p+1,p}[c][k]
-            const double* X = SBLK(p + 1, p);
-            double acc = yv[SB * (p + 1) + lane];
-            for (int k = 0; k < SB; ++k) acc = fma(-zv[SB * p + k], X[k * SB + lane], acc);
-            yv[SB * (p + 1) + lane] = acc;
-        }
-        __syncthreads();
-        // ---- wave 0 factors block (p+1, p+1) while waves 1-3 update the columns j >= p+2
-        if (wave == 0) {
-            logdet += sm_potf2(SBLK(p + 1, p + 1), Wcur, lane, SB * (p + 1), bad);
-        } else {
-            const int m = NB - p - 2;               // block columns p+2 .. NB-1
-            const int nt_ = m * (m + 1) / 2;
-            for (int t = wave - 1; t < nt_; t += 3) {
-                int ii = 0, rem = t;
-                while (rem > ii) { rem -= ii + 1; ++ii; }
-                const int i = p + 2 + ii, j = p + 2 + rem;
-                sm_update(SBLK(i, j), SBLK(i, p), SBLK(j, p), lane);
-            }
-            if (wave == 3) {
-                for (int q = lane; q < m * SB; q += 64) {
-                    const int j = p + 2 + (q >> 4), c = q & 15;
-                    const double* X = SBLK(j, p);
-                    double acc = yv[SB * j + c];
-                    for (int k = 0; k < SB; ++k) acc = fma(-zv[SB * p + k], X[k * SB + c], acc);
-                    yv[SB * j + c] = acc;
+                    for (int c = 0; c < SB; ++c) r[c] = yv[SB * p + c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < SB; ++c) r[c] = 0.0;
+                }
+                double lcc;
+                sm_factor_rows(r, li, SB * p, bad, lcc);
+                if (is_diag) {
+                    if (wave == 0) ldv[SB * p + li] = lcc;   // the factor's diagonal block itself is never read again
+                } else if (dst) {
+#pragma unroll
+                    for (int c = 0; c < SB; ++c) dst[c * SB] = r[c];
+                } else if (is_y) {
+#pragma unroll
+                    for (int c = 0; c < SB; ++c) zv[SB * p + c] = r[c];
                 }
             }
         }
         __syncthreads();
+        if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_fac += t - tq; tq = t; }
+        if (p + 1 >= NB) break;
+        // ---- trailing update: blocks (i, j), p < j <= i, dealt to the waves; right-hand side on the VALU
+        {
+            const int m = NB - p - 1;
+            const int nt_ = m * (m + 1) / 2;
+            // two independent blocks per wave and iteration: their MFMA chains interleave
+            for (int t = wave; t < nt_; t += 2 * SM_WAVES) {
+                int ii = 0, rem = t;
+                while (rem > ii) { rem -= ii + 1; ++ii; }
+                const int t2 = t + SM_WAVES;
+                if (t2 < nt_) {
+                    int i2 = 0, rem2 = t2;
+                    while (rem2 > i2) { rem2 -= i2 + 1; ++i2; }
+                    sm_update2(SBLK(p + 1 + ii, p + 1 + rem), SBLK(p + 1 + ii, p), SBLK(p + 1 + rem, p),
+                               SBLK(p + 1 + i2, p + 1 + rem2), SBLK(p + 1 + i2, p), SBLK(p + 1 + rem2, p), lane);
+                } else {
+                    sm_update(SBLK(p + 1 + ii, p + 1 + rem), SBLK(p + 1 + ii, p), SBLK(p + 1 + rem, p), lane);
+                }
+            }
+            for (int q = tid; q < m * SB; q += SM_THREADS) {     // y_j[c] -= sum_k z_p[k] X_jp[c][k]
+                const int j = p + 1 + (q >> 4), c = q & 15;
+                const double* X = SBLK(j, p);
+                double acc = yv[SB * j + c];
+#pragma unroll
+                for (int k = 0; k < SB; ++k) acc = fma(-zv[SB * p + k], X[k * SB + c], acc);
+                yv[SB * j + c] = acc;
+            }
+        }
+        __syncthreads();
+        if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_upd += t - tq; tq = t; }
     }
 
     if (wave == 0) {
-        double q = 0.0;
-        for (int i = lane; i < n; i += 64) q = fma(zv[i], zv[i], q);
+        double q = 0.0, ld = 0.0;
+        for (int i = lane; i < n; i += 64) {
+            q = fma(zv[i], zv[i], q);
+            ld += log(ldv[i]);
+        }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+        for (int o = 32; o >= 1; o >>= 1) {
+            q += __shfl_xor(q, o, 64);
+            ld += __shfl_xor(ld, o, 64);
+        }
         if (lane == 0) {
             double* o = a.out + 4 * (long long)blockIdx.x;
-            o[0] = 2.0 * logdet;
+            o[0] = 2.0 * ld;
             o[1] = q;
             o[2] = (double)bad;
             o[3] = 0.0;
+            if (a.stamps) {    // shader-clock ticks: inputs, Gram, factor+panel phases, update phases, -, total
+                double* sp = a.stamps + 8 * (long long)blockIdx.x;
+                sp[0] = (double)(t0 - tstart); sp[1] = (double)(t1 - t0); sp[2] = (double)t_fac; sp[3] = (double)t_upd;
+                sp[4] = 0.0; sp[5] = (double)(__builtin_amdgcn_s_memtime() - tstart);
+            }
         }
     }
 }
 
 size_t small_gp_lds_bytes(int n, int nF) {
     const int NB = (n + SB - 1) / SB, NP = NB * SB;
-    return ((size_t)(NB * (NB + 1) / 2) * 256 + 256 + 2 * (size_t)NP + (size_t)nF * NP) * 8;
+    return ((size_t)(NB * (NB + 1) / 2) * 256 + 3 * (size_t)NP + (size_t)nF * NP) * 8;
 }
 
 void launch_small_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st) {
     const size_t bytes = small_gp_lds_bytes(a.n, nF_max);
     static DeviceOnce once;
     lds_opt_in(once, (const void*)small_gp_logpdf_kernel, 160 * 1024);
-    hipLaunchKernelGGL(small_gp_logpdf_kernel, dim3(count), dim3(256), bytes, st, a);
+    hipLaunchKernelGGL(small_gp_logpdf_kernel, dim3(count), dim3(SM_THREADS), bytes, st, a);
 }

@@ -155,13 +155,23 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         d4 acc[4][4];
         if (ACC) {
             const double* __restrict__ Cl = Ct + (ccol * GP_TS + crow);
+            if (g.nt_c) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+                for (int n = 0; n < 4; ++n)
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
+                    for (int v = 0; v < 4; ++v)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        acc[m][n][v] = Cl[(16 * n + 4 * v) * GP_TS + 16 * m];
+                        for (int m = 0; m < 4; ++m)
+                            acc[m][n][v] = __builtin_nontemporal_load(Cl + (16 * n + 4 * v) * GP_TS + 16 * m);
+            } else {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            acc[m][n][v] = Cl[(16 * n + 4 * v) * GP_TS + 16 * m];
+            }
         } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -356,6 +366,15 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         int soff = ccol * GP_TS + crow;
         asm volatile("" : "+v"(soff));
         double* __restrict__ Cs = Ct + soff;
+        if (g.nt_c) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        __builtin_nontemporal_store(acc[m][n][v], Cs + (16 * n + 4 * v) * GP_TS + 16 * m);
+        } else {
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -363,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
                     Cs[(16 * n + 4 * v) * GP_TS + 16 * m] = acc[m][n][v];
+        }
         }
         }
         if (GP_DBG_ON(g)) {   // diagnostic stamps: go to a buffer nothing else reads

@@ -74,13 +74,13 @@ def test_failing_pivot_small_path(gp, j):
     factorisation: duplicate instances + zero noise make the Gram matrix exactly singular at the second copy."""
     n = 150
     rng = np.random.default_rng(j)
-    F = rng.standard_normal((n, 2))
+    F = 3.0 * rng.standard_normal((n, 8))     # far-apart points: the Gram matrix is close to scale * I, well conditioned
     if j > 0:
-        F[j] = F[j - 1]                   # row j duplicates row j-1: pivot j is 0 (or rounding-negative)
+        F[j] = F[j - 1]                   # row j duplicates row j-1: pivot j is exactly scale - scale = 0
     ctx = gp.Context(n, 0, 0)
     noise = 0.0 if j > 0 else -2.0        # j = 0: negative diagonal from the start
     with pytest.raises(gp.PosDefException) as ei:
-        gp.nodesLogpdf([(F, [1.0, 1.5], 1.0, noise, rng.standard_normal(n))], ctx)
+        gp.nodesLogpdf([(F, np.ones(8), 1.0, noise, rng.standard_normal(n))], ctx)
     assert ei.value.info == j + 1
     assert ctx.last_info(1)[0] == j + 1
 
