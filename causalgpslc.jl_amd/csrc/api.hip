@@ -127,6 +127,7 @@ struct gpslc_ctx {
     std::vector<int32_t> last_info;
     // cached factor of the last dense covariance given to gpslc_mvn_logpdf (SigmaU is constant per data set)
     double *mvn_tiles = nullptr, *mvn_inv = nullptr;
+    double* mvn_dense = nullptr;     // small n: the dense covariance itself (every evaluation refactorises it in LDS)
     double mvn_logdet = 0.0;
     int mvn_info = 0;
     bool mvn_valid = false;
@@ -765,6 +766,8 @@ struct HostNode {            // host view of one node (gpslc_node with plain poi
     double ls_col;
     double scale, noise;
     const double* target;
+    const double* dev_cov;   // dense-covariance node: n x n in device memory (else null), and its scale factor
+    double covscale;
 };
 
 bool small_path_fits(const gpslc_ctx* c, int nF_max) {
@@ -813,6 +816,7 @@ int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* l
         const HostNode& h = nodes[i];
         SmallNode& sn = hn[i];
         sn.nF = h.nF; sn.pad_ = 0; sn.scale = h.scale; sn.noise = h.noise;
+        sn.cov = h.dev_cov; sn.covscale = h.covscale;
         sn.Fs = dd + o;
         for (int g = 0; g < 2; ++g)
             for (int f = 0; f < h.nFpart[g]; ++f) put_scaled(h.F[g] + (size_t)f * n, h.ls[g][f]);
@@ -914,6 +918,7 @@ int gpslc_destroy(gpslc_ctx* c) {
     for (auto p : c->tri_order) if (p) (void)hipFree(p);
     if (c->mvn_tiles) (void)hipFree(c->mvn_tiles);
     if (c->mvn_inv) (void)hipFree(c->mvn_inv);
+    if (c->mvn_dense) (void)hipFree(c->mvn_dense);
     if (c->dX) (void)hipFree(c->dX);
     if (c->dT) (void)hipFree(c->dT);
     if (c->dY) (void)hipFree(c->dY);
@@ -1305,6 +1310,40 @@ int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* c
     if (!cov && !c->mvn_valid) return bad_arg(c, 3, "cov is NULL and no factor is cached");
     if (S > 0 && !x) return bad_arg(c, 5, "x is NULL");
     if (S > 0 && !logpdf) return bad_arg(c, 6, "logpdf is NULL");
+    if (!(c->flags & GPSLC_FLAG_FP32_KERNEL) && small_path_fits(c, 0) && S <= 4096) {
+        // small n: keep the dense matrix on the device; every evaluation is one workgroup that scales, factorises
+        // and solves in LDS (k_small.hip) — cheaper than the tiled forward solve against a cached factor
+        return guarded(c, [&]() {
+            const size_t n = (size_t)c->n;
+            if (cov) {
+                c->mvn_valid = false;
+                if (!c->mvn_dense) HC(hipMalloc((void**)&c->mvn_dense, n * n * sizeof(double)));
+                HC(hipMemcpy(c->mvn_dense, cov, n * n * sizeof(double), hipMemcpyHostToDevice));
+                // validate once (as the general path does when it caches the factor): info of cov itself
+                std::vector<double> zeros(n, 0.0);
+                HostNode probe{};
+                probe.dev_cov = c->mvn_dense; probe.covscale = 1.0; probe.target = zeros.data();
+                double dummy = 0.0;
+                c->mvn_info = small_nodes_logpdf(c, 1, &probe, &dummy);
+                c->mvn_valid = true;
+            }
+            c->last_info.assign((size_t)S, c->mvn_info);
+            if (S == 0 || c->mvn_info != 0) {
+                for (int64_t s = 0; s < S; ++s) logpdf[s] = NAN;
+                return c->mvn_info;
+            }
+            std::vector<HostNode> hn((size_t)S);
+            for (int64_t s = 0; s < S; ++s) {
+                hn[s] = HostNode{};
+                hn[s].dev_cov = c->mvn_dense;
+                hn[s].covscale = covscale ? covscale[s] : 1.0;
+                hn[s].target = x + s * n;
+            }
+            const int st = small_nodes_logpdf(c, (int)S, hn.data(), logpdf);
+            if (st > 0) for (int64_t s = 0; s < S; ++s) if (c->last_info[s] != 0) logpdf[s] = NAN;
+            return st;
+        });
+    }
     return guarded(c, [&]() {
         ensure_streams(c);
         const int n = (int)c->n, nt = c->nt;

@@ -229,6 +229,8 @@ struct SmallNode {
     double scale, noise;
     int nF;
     int pad_;
+    const double* cov;      // non-null: dense n x n covariance in DEVICE memory (lower triangle read); the matrix is
+    double covscale;        //   covscale * cov instead of the RBF Gram matrix (the :U => u => :U prior nodes)
 };
 #define SMALL_INLINE_NODES 4
 struct SmallArgs {

@@ -150,7 +150,11 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int w = lane + 64 * u;
-                v[u] = sm_gram_entry(fs, NP, nd.nF, n, SB * bi + (w & 15), SB * bj + (w >> 4), nd.scale, nd.noise);
+                const int i = SB * bi + (w & 15), j = SB * bj + (w >> 4);
+                if (nd.cov)        // dense covariance node (uCov = SigmaU * uNoise, src/model_likelihood.jl:4-10)
+                    v[u] = (i < n && j < n) ? nd.covscale * nd.cov[(long long)j * n + i] : (i == j ? 1.0 : 0.0);
+                else
+                    v[u] = sm_gram_entry(fs, NP, nd.nF, n, i, j, nd.scale, nd.noise);
             }
             double* B = P + (blk << 8);
 #pragma unroll

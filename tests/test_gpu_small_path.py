@@ -95,3 +95,25 @@ def test_many_nodes_one_launch(gp):
     out = gp.nodesLogpdf(nodes, gp.Context(n, 0, 0))
     for i in (0, 7, 150, 299):
         assert abs(out[i] - _ref(*nodes[i])) <= 1e-11 * abs(out[i])
+
+
+def test_dense_covariance_nodes_small_path(gp):
+    """gpslc_mvn_logpdf at small n: the dense matrix is cached on the device and every evaluation is one workgroup that
+    scales, factorises and solves in LDS (the :U => u => :U prior nodes, uCov = SigmaU * uNoise,
+    src/model_likelihood.jl:4-10); a matrix that is not positive definite is reported when it is handed over."""
+    sizes = [25, 40, 35, 30, 20]
+    n = sum(sizes)
+    SigmaU = orc.generate_sigma_u(sizes, 1e-4, 1.0)
+    rng = np.random.default_rng(11)
+    Uk = np.linalg.cholesky(SigmaU * 1.3) @ rng.standard_normal((n, 4))
+    ctx = gp.Context(n, 0, 0)
+    assert gp.mvnLogpdf(SigmaU, Uk[:, :0].reshape(n, 0), ctx=ctx).shape == (0,)      # hand over + validate only
+    sc = np.array([1.3, 0.7, 2.0, 1.0])
+    out = gp.mvnLogpdf(None, Uk, covscale=sc, ctx=ctx)
+    ref = [orc.u_node_logpdf(SigmaU, sc[k], Uk[:, k]) for k in range(4)]
+    assert np.allclose(out, ref, rtol=1e-8, atol=1e-6)
+    bad = SigmaU.copy()
+    bad[70, 70] = -1.0
+    with pytest.raises(gp.PosDefException) as ei:
+        gp.mvnLogpdf(bad, Uk[:, :0].reshape(n, 0), ctx=ctx)
+    assert ei.value.info == 71
