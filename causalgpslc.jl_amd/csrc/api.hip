@@ -770,10 +770,6 @@ struct HostNode {            // host view of one node (gpslc_node with plain poi
     double covscale;
 };
 
-bool small_path_fits(const gpslc_ctx* c, int nF_max) {
-    return small_gp_lds_bytes((int)c->n, nF_max) <= kLdsBytes;
-}
-
 void pin_reserve(gpslc_ctx* c, size_t bytes) {
     if (c->pin_bytes >= bytes) return;
     if (c->pin) { HC(hipDeviceSynchronize()); HC(hipHostFree(c->pin)); c->pin = nullptr; c->pin_bytes = 0; }
@@ -782,6 +778,15 @@ void pin_reserve(gpslc_ctx* c, size_t bytes) {
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); throw std::bad_alloc(); }
     c->pin = static_cast<char*>(p);
     c->pin_bytes = bytes;
+}
+
+// A node score can run as ONE workgroup of one launch: matrix resident in LDS (n <= 160..176), or the left-looking
+// kernel with the finished block columns in an L2-resident scratch (n <= 640).  The latter keeps one CU busy per node
+// for 100+ us: worth it up to a few hundred nodes per call, beyond that the batched tiled path wins.
+bool fast_path_ok(const gpslc_ctx* c, int nF_max, int64_t count) {
+    if (c->flags & GPSLC_FLAG_FP32_KERNEL) return false;
+    if (small_gp_lds_bytes((int)c->n, nF_max) <= kLdsBytes) return count <= 4096;
+    return mid_gp_fits((int)c->n) && count <= 512;
 }
 
 // scores `count` nodes in ONE launch; logdet/quad/info per node come back through the pinned buffer.
@@ -831,16 +836,25 @@ int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* l
     a.n = (int)n; a.NB = (int)((n + 15) / 16);
     a.out = reinterpret_cast<double*>(dev + off_out);
     a.stamps = nullptr;
+    const bool in_lds = small_gp_lds_bytes((int)n, nF_max) <= kLdsBytes;
+    if (!in_lds) {       // mid-size kernel: per-node scratch for the finished block columns and the scaled features
+        const size_t per = (mid_gp_scratch_doubles((int)n, nF_max) + 31) & ~size_t(31);
+        arena_reserve(c, c->scratch, per * (size_t)count * sizeof(double) + 256);
+        c->scratch.reset();
+        a.scratch = c->scratch.take<double>(per * (size_t)count);
+        a.scratch_stride = (long long)per;
+    }
 #ifdef GPSLC_DIAG
     static const int want_stamps = diag_env("GPSLC_SMALL_STAMPS", 0);
     if (want_stamps) a.stamps = a.out + 4 * (size_t)count;
 #endif
     hipStream_t st = c->streams[0];
-    launch_small_gp(a, count, nF_max, st);
+    if (in_lds) launch_small_gp(a, count, nF_max, st);
+    else launch_mid_gp(a, count, nF_max, st);
     HC(hipGetLastError());
     HC(hipStreamSynchronize(st));
 #ifdef GPSLC_DIAG
-    if (want_stamps) {
+    if (want_stamps && in_lds) {
         static int printed = 0;
         const double* sp = hout + 4 * (size_t)count;
         if (printed++ < want_stamps)
@@ -1161,7 +1175,7 @@ int gpslc_y_logpdf(gpslc_ctx* c, int64_t S, const double* U, const double* X_or_
     if (rc) return rc;
     if (!logpdf) return bad_arg(c, 11, "logpdf is NULL");
     if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
-    if (!(c->flags & GPSLC_FLAG_FP32_KERNEL) && small_path_fits(c, c->nU + c->nX + 1) && S <= 4096) {
+    if (fast_path_ok(c, c->nU + c->nX + 1, S)) {
         // small n: every parameter set is one workgroup of ONE launch (k_small.hip); T enters as a feature column
         return guarded(c, [&]() {
             const size_t n = (size_t)c->n;
@@ -1247,7 +1261,7 @@ int gpslc_gp_logpdf(gpslc_ctx* c, int64_t S, int32_t nF, const double* F, int32_
     if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
     return guarded(c, [&]() {
         const size_t n = (size_t)c->n;
-        if (!(c->flags & GPSLC_FLAG_FP32_KERNEL) && small_path_fits(c, nF) && S <= 4096) {
+        if (fast_path_ok(c, nF, S)) {
             std::vector<HostNode> hn((size_t)S);
             for (int64_t s = 0; s < S; ++s) {
                 HostNode& h = hn[s];
@@ -1277,7 +1291,7 @@ int gpslc_nodes_logpdf(gpslc_ctx* c, int32_t count, const gpslc_node* nodes, dou
     }
     if (count == 0) { c->last_info.clear(); return GPSLC_OK; }
     return guarded(c, [&]() {
-        if (!(c->flags & GPSLC_FLAG_FP32_KERNEL) && small_path_fits(c, nF_max)) {
+        if (fast_path_ok(c, nF_max, count)) {
             std::vector<HostNode> hn((size_t)count);
             for (int i = 0; i < count; ++i) {
                 HostNode& h = hn[i];
@@ -1310,7 +1324,7 @@ int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* c
     if (!cov && !c->mvn_valid) return bad_arg(c, 3, "cov is NULL and no factor is cached");
     if (S > 0 && !x) return bad_arg(c, 5, "x is NULL");
     if (S > 0 && !logpdf) return bad_arg(c, 6, "logpdf is NULL");
-    if (!(c->flags & GPSLC_FLAG_FP32_KERNEL) && small_path_fits(c, 0) && S <= 4096) {
+    if (fast_path_ok(c, 0, std::max<int64_t>(S, 1))) {
         // small n: keep the dense matrix on the device; every evaluation is one workgroup that scales, factorises
         // and solves in LDS (k_small.hip) — cheaper than the tiled forward solve against a cached factor
         return guarded(c, [&]() {

@@ -239,9 +239,16 @@ struct SmallArgs {
     int n, NB;              // NB = ceil(n / 16) block rows
     double* out;            // [count][4]: logdet, quad, info (1-based failing pivot, 0 = ok), reserved
     double* stamps;         // measurement build only: [count][8] phase timings, else null
+    double* scratch;        // mid-size kernel: per-node device scratch (finished block columns + scaled features)
+    long long scratch_stride;
 };
 size_t small_gp_lds_bytes(int n, int nF);
 void launch_small_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st);
+// left-looking variant for 176 < n <= 640: only the current block column in LDS, finished columns in an L2-resident scratch
+size_t mid_gp_scratch_doubles(int n, int nF);
+size_t mid_gp_lds_bytes(int n, int nF);
+bool mid_gp_fits(int n);
+void launch_mid_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st);
 
 // summarizeEstimates (src/driver.jl:129-149): per-row mean and two type-7 quantiles of an n x m sample matrix
 struct SummArgs {

@@ -264,6 +264,193 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same score for the sizes between the LDS-resident kernel and the batched tiled path (176 < n <= 640: IHDP
+// n = 272): one workgroup per node, LEFT-looking over block columns.  Only the current block column lives in LDS; the
+// finished columns X(i, k) = L blocks sit in a per-node global scratch that stays in L2 (n = 272: 306 KiB).
+// Per block column p:
+//   accumulate  every wave owns up to MID_MAXI block rows i >= p: the Gram block (i, p) is evaluated straight into the
+//               MFMA accumulator layout and  -= sum_{k<p} X(i,k) X(p,k)^T  runs with the accumulators in registers for the
+//               whole k loop (operand fragments are 512-byte coalesced reads of the scratch; X(p,k) is shared by the
+//               wave's rows) — no read-modify-write of a trailing matrix anywhere;
+//   factor+panel  exactly the register-resident column operations of the small kernel (sm_factor_rows) on the LDS
+//               image of the column, 48 rows per wave and pass;
+//   store       the column's X blocks go to the scratch for the columns to come.
+// The right-hand side rides along as block row NB (its row 0 = target, the other 15 rows zero): z = L^-1 target
+// falls out of the same block operations, no special case.  Three barriers per block column.
+// ---------------------------------------------------------------------------------------------------------------------
+#define MID_MAXI 6         // block rows per wave: (NB + 1) <= 8 * MID_MAXI  ->  NB <= 47, limited to n <= 640 by the host
+#define MBLK(i, j) (X + ((((long long)(i) * ((i) + 1)) / 2 + (j)) << 8))     // scratch: packed lower blocks, rows 0..NB
+
+__global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double P[];
+    const SmallNode nd = blockIdx.x < SMALL_INLINE_NODES ? a.inl[blockIdx.x] : a.nodes[blockIdx.x];
+    const int n = a.n, NB = a.NB, NP = NB * SB, NBa = NB + 1;
+    double* __restrict__ X = a.scratch + (long long)blockIdx.x * a.scratch_stride;     // finished columns
+    double* feat = X + ((long long)NBa * (NBa + 1) / 2) * 256;                           // scaled features [f][NP]
+    double* Cp = P;                       // current block column: slot (i - p) = block (i, p), i = p..NB
+    double* ldv = Cp + NBa * 256;         // diag(L)
+    double* fsp = ldv + NP;               // features of the 16 instances of block column p: fsp[f*16 + c]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+
+    for (int idx = tid; idx < nd.nF * NP; idx += SM_THREADS) {
+        const int f = idx / NP, i = idx - f * NP;
+        feat[idx] = (i < n) ? nd.Fs[(long long)f * n + i] : 0.0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    int bad = 0;
+
+    for (int p = 0; p < NB; ++p) {
+        for (int idx = tid; idx < nd.nF * SB; idx += SM_THREADS) fsp[idx] = feat[(idx >> 4) * NP + SB * p + (idx & 15)];
+        __syncthreads();
+        // ---- accumulate: block rows i = p + wave + 8u
+        {
+            d4 acc[MID_MAXI];
+#pragma unroll
+            for (int u = 0; u < MID_MAXI; ++u) {
+                const int i = p + wave + SM_WAVES * u;
+                acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
+                if (i < NB) {             // Gram block (i, p): element (row 16i + li, col 16p + lg + 4v)
+                    const int gi = SB * i + li;
+                    double lux[4] = {0.0, 0.0, 0.0, 0.0};
+                    for (int f = 0; f < nd.nF; ++f) {
+                        const double xr = feat[f * NP + gi];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const double d = xr - fsp[f * SB + lg + 4 * v];
+                            lux[v] = fma(d, d, lux[v]);
+                        }
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int gj = SB * p + lg + 4 * v;
+                        double val;
+                        if (gi < n && gj < n) {
+                            if (nd.cov) val = nd.covscale * nd.cov[(long long)gj * n + gi];
+                            else {
+                                val = nd.scale * gp_exp_neg(-lux[v]);
+                                if (gi == gj) val += nd.noise;
+                            }
+                        } else {
+                            val = (gi == gj) ? 1.0 : 0.0;
+                        }
+                        acc[u][v] = val;
+                    }
+                } else if (i == NB) {     // right-hand side block: row 0 = target
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int gj = SB * p + lg + 4 * v;
+                        acc[u][v] = (li == 0 && gj < n) ? nd.target[gj] : 0.0;
+                    }
+                }
+            }
+            for (int k = 0; k < p; ++k) {
+                const double* Xpk = MBLK(p, k);
+                double fj[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) fj[kk] = sm_frag(Xpk, kk, lane);
+#pragma unroll
+                for (int u = 0; u < MID_MAXI; ++u) {
+                    const int i = p + wave + SM_WAVES * u;
+                    if (i <= NB) {
+                        const double* Xik = MBLK(i, k);
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[kk], sm_frag(Xik, kk, lane), acc[u], 0, 0, 1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < MID_MAXI; ++u) {
+                const int i = p + wave + SM_WAVES * u;
+                if (i <= NB) {
+                    double* B = Cp + ((i - p) << 8);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) B[(lg + 4 * v) * SB + li] = acc[u][v];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- factor + panel on the LDS image of the column: rows below the diagonal block = 16 (NBa - p - 1)
+        {
+            const int rows = SB * (NBa - p - 1);
+            for (int q0 = 0; q0 < rows; q0 += 48 * SM_WAVES) {
+                if (q0 + wave * 48 < rows) {                                 // wave-uniform: this wave carries rows
+                    const bool is_diag = lane < SB;
+                    const int q = q0 + wave * 48 + (lane - SB);
+                    double r[SB];
+                    double* dst = nullptr;
+                    if (is_diag) dst = Cp + li;
+                    else if (q < rows) dst = Cp + (((q >> 4) + 1) << 8) + (q & 15);
+                    if (dst) {
+#pragma unroll
+                        for (int c = 0; c < SB; ++c) r[c] = dst[c * SB];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < SB; ++c) r[c] = 0.0;
+                    }
+                    double lcc;
+                    sm_factor_rows(r, li, SB * p, bad, lcc);
+                    if (is_diag) {
+                        if (wave == 0 && q0 == 0) ldv[SB * p + li] = lcc;
+                    } else if (dst) {
+#pragma unroll
+                        for (int c = 0; c < SB; ++c) dst[c * SB] = r[c];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- store the column's X blocks (i > p) for the columns to come
+        for (int idx = tid; idx < (NBa - p - 1) * 256; idx += SM_THREADS) {
+            const int i = p + 1 + (idx >> 8);
+            MBLK(i, p)[idx & 255] = Cp[256 + idx];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+
+    if (wave == 0) {      // z = row 0 of the right-hand side blocks (NB, k): z[16k + c] = X(NB, k)[c*16 + 0]
+        double q = 0.0, ld = 0.0;
+        for (int i = lane; i < n; i += 64) {
+            const double z = MBLK(NB, i >> 4)[(i & 15) * SB];
+            q = fma(z, z, q);
+            ld += log(ldv[i]);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            q += __shfl_xor(q, o, 64);
+            ld += __shfl_xor(ld, o, 64);
+        }
+        if (lane == 0) {
+            double* o = a.out + 4 * (long long)blockIdx.x;
+            o[0] = 2.0 * ld;
+            o[1] = q;
+            o[2] = (double)bad;
+            o[3] = 0.0;
+        }
+    }
+}
+
+size_t mid_gp_scratch_doubles(int n, int nF) {
+    const long long NB = (n + SB - 1) / SB, NBa = NB + 1;
+    return (size_t)(NBa * (NBa + 1) / 2 * 256 + (long long)nF * NB * SB);
+}
+size_t mid_gp_lds_bytes(int n, int nF) {
+    const int NB = (n + SB - 1) / SB;
+    return ((size_t)(NB + 1) * 256 + (size_t)NB * SB + (size_t)nF * SB) * 8;
+}
+bool mid_gp_fits(int n) { return (n + SB - 1) / SB + 1 <= SM_WAVES * MID_MAXI && n <= 640; }
+
+void launch_mid_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st) {
+    const size_t bytes = mid_gp_lds_bytes(a.n, nF_max);
+    static DeviceOnce once;
+    lds_opt_in(once, (const void*)mid_gp_logpdf_kernel, 160 * 1024);
+    hipLaunchKernelGGL(mid_gp_logpdf_kernel, dim3(count), dim3(SM_THREADS), bytes, st, a);
+}
+
 size_t small_gp_lds_bytes(int n, int nF) {
     const int NB = (n + SB - 1) / SB, NP = NB * SB;
     return ((size_t)(NB * (NB + 1) / 2) * 256 + 3 * (size_t)NP + (size_t)nF * NP) * 8;

@@ -19,10 +19,11 @@ def _ref(F, ls, scale, noise, target):
     return orc.mvnormal_logpdf(np.asarray(target, dtype=float), cov)
 
 
-@pytest.mark.parametrize("n", [1, 5, 15, 16, 17, 31, 33, 100, 150, 160, 176, 177, 200])
+@pytest.mark.parametrize("n", [1, 5, 15, 16, 17, 31, 33, 100, 150, 160, 176, 177, 200, 272, 400, 513, 640, 641])
 def test_heterogeneous_nodes_one_call(gp, n):
-    """Nodes with different feature counts in one call; n = 176 is the last size that fits the LDS-resident path with
-    these feature counts, 177 and 200 take the general tiled path node by node: same answers."""
+    """Nodes with different feature counts in one call; n = 176 is the last size that fits the LDS-resident kernel with
+    these feature counts, 177..640 run the left-looking single-workgroup kernel (finished block columns in an L2-resident
+    scratch; IHDP's n = 272), 641 takes the general tiled path node by node: same answers."""
     rng = np.random.default_rng(1000 + n)
     ctx = gp.Context(n, 0, 0)
     nodes = []
@@ -40,7 +41,7 @@ def test_heterogeneous_nodes_one_call(gp, n):
 
 
 def test_wide_feature_block_limits(gp):
-    """nF = 32 fits up to n = 160; n = 161..176 with nF = 32 must fall back to the general path, silently."""
+    """nF = 32 fits the LDS-resident kernel up to n = 160; n = 170 with nF = 32 silently takes the left-looking one."""
     rng = np.random.default_rng(5)
     for n in (160, 170):
         F = rng.standard_normal((n, 32))

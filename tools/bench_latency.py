@@ -13,7 +13,7 @@ import causalgpslc_jl_amd as gp   # noqa: E402
 if "--diag-lib" in sys.argv:      # measurement build (phase stamps of the small kernel with GPSLC_SMALL_STAMPS=<count>)
     gp._lib.LIB_PATH = gp._lib.LIB_PATH.replace("libgpslc_hip.so", "libgpslc_hip_diag.so")
 
-for n, F in ((150, 2), (150, 8), (160, 3), (272, 8), (1000, 8)):
+for n, F in ((150, 2), (150, 8), (160, 3), (272, 8), (400, 8), (640, 8), (641, 8), (1000, 8)):
     rng = np.random.default_rng(n)
     Fm = rng.standard_normal((n, F))
     ls = 1.0 + rng.random(F)
