@@ -346,9 +346,11 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
                     }
                 }
             }
-            for (int k = 0; k < p; ++k) {
+            // k loop, software-pipelined by hand: the fragments of step k+1 are in flight (L2 latency ~1 us) while the
+            // MFMAs of step k run; two register sets, loop unrolled by two so that their indices are static
+            double fj0[4], fj1[4], fi0[MID_MAXI][4], fi1[MID_MAXI][4];
+            auto fetch = [&](int k, double (&fj)[4], double (&fi)[MID_MAXI][4]) {
                 const double* Xpk = MBLK(p, k);
-                double fj[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) fj[kk] = sm_frag(Xpk, kk, lane);
 #pragma unroll
@@ -357,9 +359,28 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
                     if (i <= NB) {
                         const double* Xik = MBLK(i, k);
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-                            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[kk], sm_frag(Xik, kk, lane), acc[u], 0, 0, 1);
+                        for (int kk = 0; kk < 4; ++kk) fi[u][kk] = sm_frag(Xik, kk, lane);
                     }
+                }
+            };
+            auto apply = [&](const double (&fj)[4], const double (&fi)[MID_MAXI][4]) {
+#pragma unroll
+                for (int u = 0; u < MID_MAXI; ++u) {
+                    const int i = p + wave + SM_WAVES * u;
+                    if (i <= NB) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[kk], fi[u][kk], acc[u], 0, 0, 1);
+                    }
+                }
+            };
+            if (p > 0) fetch(0, fj0, fi0);
+            for (int k = 0; k < p; k += 2) {
+                if (k + 1 < p) fetch(k + 1, fj1, fi1);
+                apply(fj0, fi0);
+                if (k + 1 < p) {
+                    if (k + 2 < p) fetch(k + 2, fj0, fi0);
+                    apply(fj1, fi1);
                 }
             }
 #pragma unroll
