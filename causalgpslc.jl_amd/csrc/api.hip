@@ -621,7 +621,10 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                         GemmArgs g{};
                         g.A = W; g.C = W;
                         g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = nt; g.mj = 1; g.nbatch = ub; g.ntiles = nt;
-                        if (k > 0 && fuse_mode()) {
+                        // fused up to a K depth of w_fuse_maxk tiles: beyond it the separate (HBM-bound) panel product is
+                        // a small share and the plain update kernel's higher MFMA rate wins (measured, profiles/)
+                        static const int w_fuse_maxk = diag_env("GPSLC_FUSE_W_MAXK", 32);
+                        if (k > 0 && k <= w_fuse_maxk && fuse_mode()) {
                             g.B = Ls; g.k0 = 0; g.k1 = k; g.accumulate = 1;
                             g.fuse = 1; g.F = invref; g.fk = k;
                             gemm(c, g, st, 3);

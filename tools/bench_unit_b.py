@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import causalgpslc_jl_amd as gp          # noqa: E402
 from causalgpslc_jl_amd import synth    # noqa: E402
 
+if "--diag-lib" in sys.argv:      # measurement build (GPSLC_* switches live there only)
+    sys.argv.remove("--diag-lib")
+    gp._lib.LIB_PATH = gp._lib.LIB_PATH.replace("libgpslc_hip.so", "libgpslc_hip_diag.so")
 n, S, L, spp = (int(a) for a in (sys.argv[1:5] + ["4096", "128", "1", "8"][len(sys.argv) - 1:]))
 D, K = 8, 2
 X, T, Y, obj = synth.make_dataset(n, D)
