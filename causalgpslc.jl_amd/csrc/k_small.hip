@@ -53,23 +53,38 @@ __device__ __forceinline__ double sm_frag(const double* blk, int kk, int lane) {
 // reads.  Every other lane holds a row below the block (or the right-hand side) and ends up holding that row of
 // A_ip L_pp^-T.  Nothing but the pivot chain sits in the loop: readlane -> rsq -> 4 dependent flops -> scale -> first
 // update -> next readlane.  bad = 1-based first non-positive pivot (0 = ok), wave-uniform.
+// y = d^-1/2: hardware estimate (~2^-23) + one third-order step (error^3 ~ 2^-69)
+__device__ __forceinline__ double sm_rsqrt(double d) {
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y0, y0, 1.0);
+    return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+
 __device__ __forceinline__ void sm_factor_rows(double (&r)[SB], int li, int base, int& bad, double& lcc) {
     double dsave = 1.0, ysave = 1.0;          // pivot and its reciprocal square root of THIS lane's column (lane c: column c)
+    double d = sm_readlane(r[0], 0);          // pivot: row c of the diagonal block lives in lane c
+    double y = sm_rsqrt(d);
 #pragma unroll
     for (int c = 0; c < SB; ++c) {
-        const double d = sm_readlane(r[c], c);                 // pivot: row c of the diagonal block lives in lane c
         if (!(d > 0.0) && bad == 0) bad = base + c + 1;
-        // y = d^-1/2: hardware estimate (~2^-23) + one third-order step (error^3 ~ 2^-69)
-        const double y0 = __builtin_amdgcn_rsq(d);
-        const double e = fma(-d * y0, y0, 1.0);
-        const double y = fma(y0 * e, fma(e, 0.375, 0.5), y0);
+        if (li == c) { dsave = d; ysave = y; }
         r[c] *= y;
+        // software-pipelined by hand: update column c+1 first and START the next pivot's reciprocal square root, so that
+        // its dependent chain runs under the remaining 14 - c column updates instead of after them
+        double dn = 1.0, yn = 1.0;
+        if (c + 1 < SB) {
+            const double l1 = sm_readlane(r[c], c + 1);        // L[c+1][c]: row c+1 of the diagonal block = lane c+1
+            r[c + 1] = fma(-r[c], l1, r[c + 1]);
+            dn = sm_readlane(r[c + 1], c + 1);
+            yn = sm_rsqrt(dn);
+        }
 #pragma unroll
-        for (int j = c + 1; j < SB; ++j) {
+        for (int j = c + 2; j < SB; ++j) {
             const double ljc = sm_readlane(r[c], j);           // L[j][c], row j of the diagonal block = lane j
             r[j] = fma(-r[c], ljc, r[j]);
         }
-        if (li == c) { dsave = d; ysave = y; }
+        d = dn;
+        y = yn;
     }
     // L_cc = sqrt(pivot_c): d*y with one Newton correction, once per lane, off the chain
     double sq = dsave * ysave;
