@@ -378,7 +378,8 @@ TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstri
 // trailing (ntot-nt)^2 block its Schur complement.  Panels of `pw` tile columns: left-looking inside a
 // panel, one right-looking trailing update (K = pw*128) per panel.
 void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, long long inv_bstride,
-                 int* info, int info_base, int nb, hipStream_t st, int aug_rows = 0, int prof_base = 0) {
+                 int* info, int info_base, int nb, hipStream_t st, int aug_rows = 0, int prof_base = 0,
+                 bool robust = false) {
     // aug_rows > 0: the tile rows nt.. hold only that many live rows in total (right-hand sides);
     // a single augmented tile row is the common case and the only one the kernel shortens
     const int short_rows = (aug_rows > 0 && ntot == nt + 1) ? aug_rows : 0;
@@ -388,6 +389,35 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
     for (size_t i = 0; i < c->streams.size() && i < c->queues.size(); ++i)
         if (c->streams[i] == st) HC(hipMemsetAsync(c->queues[i], 0, 16 * sizeof(int), st));
     TRef invref = TRef{inv, inv_bstride, 1, 0, 0, 0};   // tile (j, kk) -> inv[kk]
+    if (robust && ntot == nt) {
+        // Near-singular matrices (CovITE + 1e-10 I, SigmaU with its 1e-13 jitter): no multiplication by an inverted block
+        // anywhere — the diagonal tile and the panel below it are solved by substitution (k_robust.hip); the column and
+        // trailing updates stay on the MFMA tile kernel (a product is backward stable whatever the conditioning).
+        for (int k = 0; k < nt; ++k) {
+            const int ka = (k / pw) * pw;
+            const int kend = std::min(ka + pw, nt);
+            if (k > ka) {
+                GemmArgs g{};
+                g.A = M; g.B = M; g.C = M;
+                g.shape = 1; g.i0 = k; g.j0 = k; g.mi = nt - k; g.mj = 1; g.sym = col_sym_mode();
+                g.k0 = ka; g.k1 = k; g.accumulate = 1; g.nbatch = nb; g.ntiles = g.mi;
+                gemm(c, g, st, prof_base);
+            }
+            launch_diag_robust(M, k, info, info_base, nb, st);
+            launch_trsm_robust(M, M, k, k + 1, nt - k - 1, nb, st);
+            if (k == kend - 1 && nt - kend > 0) {
+                GemmArgs g{};
+                g.A = M; g.B = M; g.C = M;
+                const int m = nt - kend;
+                g.shape = 0; g.i0 = kend; g.j0 = kend; g.mi = m; g.mj = m; g.sym = sym_mode();
+                g.k0 = ka; g.k1 = kend; g.accumulate = 1; g.nbatch = nb; g.ntiles = m * (m + 1) / 2;
+                g.order = tri_order(c, m);
+                gemm(c, g, st, prof_base);
+            }
+        }
+        HC(hipGetLastError());
+        return;
+    }
     for (int k = 0; k < nt; ++k) {
         const int ka = (k / pw) * pw;
         const int kend = std::min(ka + pw, nt);
@@ -651,7 +681,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                         launch_gather_cov(gc, ub, st);
                     }
                     if (want_draws) {
-                        potrf_tiles(c, Cm, nt, nt, inv2, inv_bs, io.info + s0 + u0, n, ub, st, 0, 3);
+                        potrf_tiles(c, Cm, nt, nt, inv2, inv_bs, io.info + s0 + u0, n, ub, st, 0, 3, /*robust=*/true);
                         DrawArgs dr{};
                         dr.Lc = Cm; dr.n = n; dr.nt = nt; dr.s0 = s0 + u0; dr.S = io.S; dr.l = l; dr.L = L;
                         dr.spp = io.spp; dr.mean = meanITE; dr.z = io.z; dr.zgen = zgen; dr.seed = io.seed;
@@ -1376,7 +1406,8 @@ int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* c
             HC(hipMemsetAsync(info.p, 0, sizeof(int), st));
             TRef M = lower_ref(c->mvn_tiles, nlow * GP_TSQ);
             launch_dense_load(DenseLoadArgs{dcov, n, nt, M}, st);
-            potrf_tiles(c, M, nt, nt, c->mvn_inv, (long long)nt * GP_TSQ, info.as<int>(), 0, 1, st);
+            // by substitution: SigmaU * uNoise is near-singular by construction (1e-13 jitter, src/utils.jl:17-33)
+            potrf_tiles(c, M, nt, nt, c->mvn_inv, (long long)nt * GP_TSQ, info.as<int>(), 0, 1, st, 0, 0, /*robust=*/true);
             launch_quad_rows(QuadRowsArgs{M, n, nt, 0, 0, old.as<double>(), oq.as<double>()}, st);
             HC(hipStreamSynchronize(st));
             HC(hipGetLastError());
@@ -1397,17 +1428,12 @@ int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* c
         double* oq = c->io.take<double>((size_t)S);
         TRef W = rect_ref(wt, (long long)naug * nt * GP_TSQ, nt);
         TRef Ls = lower_ref(c->mvn_tiles, nlow * GP_TSQ);
-        TRef invref = TRef{c->mvn_inv, (long long)nt * GP_TSQ, 1, 0, 0, 0};
         launch_rows_rhs(RowsRhsArgs{dx, S, n, nt, naug, W, 0, 1}, st);
         const int short_rows = naug == 1 ? (int)S : 0;
-        // right-looking: z_k = w_k inv(L_kk)^T, then every remaining column block in parallel
+        // right-looking: z_k = w_k L_kk^-T by substitution (no inverted block: the factor is near-singular), then every
+        // remaining column block in parallel on the MFMA tile kernel
         for (int k = 0; k < nt; ++k) {
-            GemmArgs g{};
-            g.A = W; g.B = invref; g.C = W;
-            g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = naug; g.mj = 1;
-            g.k0 = k; g.k1 = k + 1; g.accumulate = 0; g.nbatch = 1; g.ntiles = naug;
-            g.short_row0 = 0; g.short_rows = short_rows;
-            gemm(c, g, st);
+            launch_trsm_robust(W, Ls, k, 0, naug, 1, st);
             if (k + 1 < nt) {   // W(:, j) -= W(:, k) L(j, k)^T for j > k
                 GemmArgs u{};
                 u.A = W; u.B = Ls; u.C = W;

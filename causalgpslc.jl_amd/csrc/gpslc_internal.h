@@ -133,6 +133,9 @@ void launch_syrk_diag(const GemmArgs& g, int carry_aug, hipStream_t st);   // g.
 void launch_diag(const TRef& M, int k, double* inv, long long inv_bstride, int* info,
                  int info_base, int nbatch, hipStream_t st);
 void launch_gram(const GramArgs& g, int nbatch, hipStream_t st);
+// substitution-based (backward-stable) diagonal-tile factorisation and panel solve for near-singular matrices (k_robust.hip)
+void launch_diag_robust(const TRef& M, int k, int* info, int info_base, int nbatch, hipStream_t st);
+void launch_trsm_robust(const TRef& X, const TRef& L, int k, int i0, int count, int nbatch, hipStream_t st);
 
 struct RhsArgs {
     const double* T; const double* Y; const double* tyLS; const double* doT;

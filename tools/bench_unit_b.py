@@ -20,7 +20,7 @@ X, T, Y, obj = synth.make_dataset(n, D)
 post = synth.make_posterior(n, D, K, S, obj, seed=1234)
 g = gp.GPSLCObject(X, T, Y, post["U"], post["uyLS"], post["xyLS"], post["tyLS"], post["yNoise"], post["yScale"])
 doTs = synth.levels(T, L)
-gp.predict(g, doTs[:1], spp=2, seed=1, want_draws=True)     # warm-up (arenas, first-touch)
+gp.predict(g, doTs[:1], spp=spp, seed=1, want_draws=True)     # warm-up (arenas sized for this spp, first touch)
 t0 = time.perf_counter()
 ms, vs, mi, dr = gp.predict(g, doTs, spp=spp, seed=7, want_draws=True)
 dt = time.perf_counter() - t0
