@@ -7,7 +7,7 @@
 // the panel is one more f64-MFMA product.  A product with a computed inverse carries an error of eps * cond(L_kk); for
 // A = K + yNoise I (cond(L) ~ 1e2..1e3) that is rounding noise, for a near-singular leading block (cond(L) ~ 1e5) it
 // reaches the 1e-10 jitter and a pivot of the trailing block goes negative although LAPACK's potrf succeeds on the very
-// same matrix — measured on the reference's documented NEEC example (tools/_chk_neec_pd.py: pivot 135 of a 150 x 150
+// same matrix — measured on the reference's documented NEEC example (tools/check_neec_pd.py: pivot 135 of a 150 x 150
 // CovITE + 1e-10 I, numpy.linalg.cholesky fine).  Substitution is backward stable whatever the conditioning.
 //
 // How: the column operations of k_small.hip's register-resident Cholesky (sm_blocks.h).  The Cholesky of a 16 x 16

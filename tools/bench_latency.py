@@ -38,3 +38,8 @@ gp.gpslc(neec, seed=1)
 t0 = time.perf_counter()
 g = gp.gpslc(neec, seed=1234)
 print(f"gpslc(NEEC_sampled.csv), default hyper-parameters: {time.perf_counter() - t0:.2f} s", flush=True)
+ihdp = os.path.join(ROOT, "tests", "golden", "neec", "IHDP_sampled.csv")
+t0 = time.perf_counter()
+g = gp.gpslc(ihdp, seed=1234)
+print(f"gpslc(IHDP_sampled.csv: n = 272, 6 covariates, binary treatment), default hyper-parameters: {time.perf_counter() - t0:.2f} s",
+      flush=True)
