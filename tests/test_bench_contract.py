@@ -1,0 +1,53 @@
+"""Host-side checks of bench.py's contract (no GPU): --gpus N never yields a silent 1-GPU number, the committed PMC
+summary is tied to the kernel source it was taken from, and the JSON keys the driver reads are spelled as promised."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    if env:
+        e.update(env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_gpus_flag_refuses_a_box_with_fewer_gpus():
+    r = _run(["--gpus", "8", "--steps", "1"])          # this container has no GPU at all
+    assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "4", "--steps", "1"], env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 3 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
+
+
+def test_pmc_summary_is_tied_to_the_kernel_source():
+    sys.path.insert(0, ROOT)
+    import bench
+    pm = json.load(open(bench.PMC_SUMMARY))
+    assert set(("hbm_bytes_per_launch", "kernel_src_sha")) <= set(pm)
+    data = open(bench.KERNEL_SRC, "rb").read()
+    sha = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    assert bench.git_blob_sha(bench.KERNEL_SRC) == sha
+    # committed together: the summary describes the kernel in this tree (bench.py withholds `traffic` otherwise)
+    assert pm["kernel_src_sha"] == sha, "k_tilegemm.hip changed: re-run tools/profile_r02.sh + tools/collect_profiles.py"
+
+
+def test_committed_bench_line_carries_the_contract_keys():
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "sate_rel_err", "units"):
+        assert k in d, k
+    assert d["metric"].endswith("SATE rel-err vs CPU") and "workload" in d["config"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
+    assert d["sate_rel_err"]["ok"] and d["sate_rel_err"]["mean"] < 1e-6 and d["sate_rel_err"]["var"] < 1e-6
+    assert {"A", "B", "C"} <= set(d["units"])
