@@ -223,6 +223,9 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
         const int f = idx / NP, i = idx - f * NP;
         feat[idx] = (i < n) ? nd.Fs[(long long)f * n + i] : 0.0;
     }
+    // the right-hand side too: it is read once per block column, and nd.target lives in pinned HOST memory
+    double* tgt = feat + (long long)nd.nF * NP;
+    for (int i = tid; i < NP; i += SM_THREADS) tgt[i] = (i < n) ? nd.target[i] : 0.0;
     __threadfence_block();
     __syncthreads();
     int bad = 0;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int gj = SB * p + lg + 4 * v;
-                        acc[u][v] = (li == 0 && gj < n) ? nd.target[gj] : 0.0;
+                        acc[u][v] = (li == 0) ? tgt[gj] : 0.0;
                     }
                 }
             }
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
 
 size_t mid_gp_scratch_doubles(int n, int nF) {
     const long long NB = (n + SB - 1) / SB, NBa = NB + 1;
-    return (size_t)(NBa * (NBa + 1) / 2 * 256 + (long long)nF * NB * SB);
+    return (size_t)(NBa * (NBa + 1) / 2 * 256 + (long long)(nF + 1) * NB * SB);
 }
 size_t mid_gp_lds_bytes(int n, int nF) {
     const int NB = (n + SB - 1) / SB;

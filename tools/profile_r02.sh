@@ -22,7 +22,7 @@ grep '"metric"' $OUT/trace.log | cut -c1-300
 tail -1 $OUT/trace_b.log
 cd $GRAFT_REPO_ROOT
 python3 tools/kernel_stats_md.py $OUT/trace "rocprofv3 --kernel-trace --stats of \`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-units\` (4 x 1024 posterior samples of unit A at N=4096 D=8 nU=2: 1 warm-up + 3 timed steps)" 4096 > $OUT/kernel_stats.md
-python3 tools/kernel_stats_md.py $OUT/trace_b "rocprofv3 --kernel-trace --stats of \`python3 tools/bench_unit_b.py 4096 64 1 10\` (2 x 64 (sample, level) units of B + C at N=4096: warm-up call with 2 draws, timed call with 10 draws per unit)" 0 > $OUT/kernel_stats_unit_b.md
+python3 tools/kernel_stats_md.py $OUT/trace_b "rocprofv3 --kernel-trace --stats of \`python3 tools/bench_unit_b.py 4096 64 1 10\` (2 x 64 (sample, level) units of B + C at N=4096: warm-up call + timed call, 10 draws per unit)" 0 > $OUT/kernel_stats_unit_b.md
 mkdir -p $OUT/pmcA $OUT/pmcB
 cp -r $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmcA/ ; cp -r $OUT/b_pmc_fetch $OUT/b_pmc_write $OUT/pmcB/
 python3 tools/pmc_summary.py $OUT/pmcA "tile_gemm_nt_kernel<1, 0, 0>" $OUT/pmc_tile_gemm.json > $OUT/pmc_tile_gemm.md
