@@ -66,7 +66,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-units", type=int, default=3)
     ap.add_argument("--no-units", action="store_true", help="skip the unit B / unit C measurements")
-    ap.add_argument("--unit-b-samples", type=int, default=64)
+    ap.add_argument("--unit-b-samples", type=int, default=8, help="posterior samples of the unit B / C measurement")
+    ap.add_argument("--unit-b-levels", type=int, default=16, help="intervention levels per posterior sample (they share one factor of A)")
     ap.add_argument("--unit-b-spp", type=int, default=10, help="draws per (sample, level): the reference's default")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--binary-t", action="store_true", help="Bernoulli(0.5) treatments (BASELINE config 5 shape)")
@@ -148,11 +149,15 @@ def cpu_baseline(n, D, K, units, X, T, Y, post, doT):
 
 
 def measure_units(gp, synth, np, torch, a, dev, local_rank, X, T, Y, obj, dX, dT, dY):
-    """SURVEY §8d units B and C on this GPU (after the timed region; inputs resident in HBM)."""
+    """SURVEY §8d units B and C on this GPU (after the timed region; inputs resident in HBM).
+
+    Unit B is defined GIVEN the factor of A ("one (sample, level) full-ITE unit given L"): the measurement sweeps
+    `--unit-b-levels` intervention levels per posterior sample, the shape of predictCounterfactualEffects
+    (src/prediction.jl:30-33), so the unit-A work of a sample is shared by its levels; the single-level case
+    (64 samples x 1 level, unit-A work of every sample included) is reported beside it."""
     n, D, K = a.n, a.d, a.nu
-    Sb, spp = a.unit_b_samples, a.unit_b_spp
-    post = synth.make_posterior(n, D, K, Sb, obj, seed=4321)
-    doT = synth.levels(T, 1)
+    spp = a.unit_b_spp
+    ctx = gp.Context(n, D, K, device=local_rank, profile=True, fp32_kernel=a.fp32_kernel)
 
     def to_dev(x):
         return None if x is None else torch.from_numpy(np.ascontiguousarray(x.reshape(-1, order="F"))).to(dev)
@@ -160,38 +165,50 @@ def measure_units(gp, synth, np, torch, a, dev, local_rank, X, T, Y, obj, dX, dT
     def ptr(t):
         return None if t is None else C.c_void_p(t.data_ptr())
 
-    packs = [to_dev(post[k]) for k in ("U", "uyLS", "xyLS", "tyLS", "yScale", "yNoise")]
-    ddo = to_dev(doT)
-    mI = torch.empty(n * Sb, dtype=torch.float64, device=dev)
-    dr = torch.empty(n * Sb * spp, dtype=torch.float64, device=dev)
-    ctx = gp.Context(n, D, K, device=local_rank, profile=True, fp32_kernel=a.fp32_kernel)
     ctx.check(ctx.lib.gpslc_set_data_dev(ctx.h, ptr(dX), ptr(dT), ptr(dY)))
 
-    def run():
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        st = ctx.lib.gpslc_predict_dev(ctx.h, Sb, *[ptr(t) for t in packs], 1, ptr(ddo), 1e-10, spp, 7, None,
-                                       None, None, ptr(mI), ptr(dr))
-        ctx.check(st)
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
+    def run_case(Sb, Lb):
+        post = synth.make_posterior(n, D, K, Sb, obj, seed=4321)
+        doT = synth.levels(T, Lb)
+        packs = [to_dev(post[k]) for k in ("U", "uyLS", "xyLS", "tyLS", "yScale", "yNoise")]
+        ddo = to_dev(doT)
+        mI = torch.empty(n * Sb * Lb, dtype=torch.float64, device=dev)
+        dr = torch.empty(n * Sb * Lb * spp, dtype=torch.float64, device=dev)
 
-    run()                   # warm-up: workspace allocation, first touch
-    ctx.profile_reset()
-    dt = run()
-    draws_l, draws_ms, draws_n = ctx.profile_get(2)
-    assert bool(torch.isfinite(dr).all()), "non-finite predictive draws"
-    info = ctx.last_info(Sb)
-    assert not info.any(), f"CovITE factorisation broke down: info = {info[info != 0][:4]}"
+        def run():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = ctx.lib.gpslc_predict_dev(ctx.h, Sb, *[ptr(t) for t in packs], Lb, ptr(ddo), 1e-10, spp, 7, None,
+                                           None, None, ptr(mI), ptr(dr))
+            ctx.check(st)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        run()                   # warm-up: workspace allocation, first touch
+        ctx.profile_reset()
+        dt = run()
+        prof = ctx.profile_get(2)
+        assert bool(torch.isfinite(dr).all()), "non-finite predictive draws"
+        info = ctx.last_info(Sb)
+        assert not info.any(), f"CovITE factorisation broke down: info = {info[info != 0][:4]}"
+        return dt, prof
+
     flop_b = 7.0 / 3.0 * float(n) ** 3
-    out = {"B": {"what": "one (sample, level) unit: W = D L^-T, CovITE + jitter = Delta - W W', its Cholesky "
-                         "(src/estimation.jl:36-50, 82, 95-109); timed with the unit-A work and the draws of those "
-                         "units included",
-                 "value": Sb / dt, "unit": "(sample, level) units/s", "samples": Sb, "levels": 1, "spp": spp,
+    Sb, Lb = a.unit_b_samples, a.unit_b_levels
+    dt, (draws_l, draws_ms, draws_n) = run_case(Sb, Lb)
+    dt1, _ = run_case(64, 1)
+    units = Sb * Lb
+    out = {"B": {"what": "one (sample, level) unit given the factor of A: W = D L^-T, CovITE + jitter = Delta - W W', its "
+                         "Cholesky (src/estimation.jl:36-50, 82, 95-109); the levels of a sample share its factor of A "
+                         "(src/prediction.jl:30-33); the timed call also computes those factors, MeanITE and the draws",
+                 "value": units / dt, "unit": "(sample, level) units/s", "samples": Sb, "levels": Lb, "spp": spp,
                  "ms": 1e3 * dt, "bound": "mfma", "algorithmic_flop_per_unit": flop_b,
-                 "achieved": Sb * flop_b / dt / 1e12, "peak": FP64_PEAK_TFLOPS, "roofline_unit": "TFLOP/s",
-                 "frac": Sb * flop_b / dt / 1e12 / FP64_PEAK_TFLOPS,
-                 "ceiling_units_per_s": FP64_PEAK_TFLOPS * 1e12 / flop_b}}
+                 "achieved": units * flop_b / dt / 1e12, "peak": FP64_PEAK_TFLOPS, "roofline_unit": "TFLOP/s",
+                 "frac": units * flop_b / dt / 1e12 / FP64_PEAK_TFLOPS,
+                 "ceiling_units_per_s": FP64_PEAK_TFLOPS * 1e12 / flop_b,
+                 "single_level": {"samples": 64, "levels": 1, "value": 64 / dt1, "ms": 1e3 * dt1,
+                                  "frac": 64 * flop_b / dt1 / 1e12 / FP64_PEAK_TFLOPS,
+                                  "note": "every unit pays its own unit-A work (Gram + factor of A + MeanITE) here"}}}
     if draws_l > 0 and draws_ms > 0:
         sec = draws_ms * 1e-3
         bytes_draw = 4.0 * float(n) ** 2           # one draw on its own reads the factor once (trmv)

@@ -379,7 +379,7 @@ TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstri
 // panel, one right-looking trailing update (K = pw*128) per panel.
 void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, long long inv_bstride,
                  int* info, int info_base, int nb, hipStream_t st, int aug_rows = 0, int prof_base = 0,
-                 bool robust = false) {
+                 bool robust = false, int info_div = 1) {
     // aug_rows > 0: the tile rows nt.. hold only that many live rows in total (right-hand sides);
     // a single augmented tile row is the common case and the only one the kernel shortens
     const int short_rows = (aug_rows > 0 && ntot == nt + 1) ? aug_rows : 0;
@@ -403,7 +403,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
                 g.k0 = ka; g.k1 = k; g.accumulate = 1; g.nbatch = nb; g.ntiles = g.mi;
                 gemm(c, g, st, prof_base);
             }
-            launch_diag_robust(M, k, info, info_base, nb, st);
+            launch_diag_robust(M, k, info, info_base, nb, st, info_div);
             launch_trsm_robust(M, M, k, k + 1, nt - k - 1, nb, st);
             if (k == kend - 1 && nt - kend > 0) {
                 GemmArgs g{};
@@ -525,7 +525,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
 
     // unit-B sub-batch (full ITE covariance): W (nt^2 tiles) + Cm (nlow tiles) + inv (nt tiles)
     const bool unitB = want_cov || want_draws;
-    const size_t unitB_per = unitB ? (size_t)((long long)nt * nt + nlow + nt) * GP_TSQ * 8 : 0;
+    const size_t unitB_per = unitB ? (size_t)((long long)nt * nt + nlow) * GP_TSQ * 8 : 0;
 
     size_t per = (size_t)tiles_per * GP_TSQ * 8      // tiles
                + (size_t)nt * GP_TSQ * 8             // inv
@@ -540,13 +540,17 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         Bb_target = (int)std::max<long long>(1, std::min<long long>(128, 65536LL / ((long long)nt * nt)));
     }
     // draws: normals workspace of one level of the sub-batch + the level-sweep staging buffer (see the unit-B loop)
+    // (per unit of the sub-batch: the staging buffer holds max(1, Bb / L) samples x L levels <= Bb pairs, or one sample's
+    // L > Bb levels — sized below through the extra term)
     const size_t draws_per = want_draws ? ((io.z ? 0 : (size_t)io.spp * n * 8 + 256) +
-                                           (L > 1 ? (size_t)L * io.spp * n * 8 + 256 : 0)) : 0;
+                                           (L > 1 ? (size_t)io.spp * n * 8 + 256 : 0)) : 0;
     const size_t unitB_all = unitB_per + draws_per;
-    const size_t fixed = (size_t)Bb_target * unitB_all + (1 << 20);
+    const size_t dtmp_extra = (want_draws && L > Bb_target) ? (size_t)(L - Bb_target) * io.spp * n * 8 : 0;
+    const size_t fixed = (size_t)Bb_target * unitB_all + dtmp_extra + (1 << 20);
     const int Bt = auto_batch(c, io.S, per, fixed);
-    const int Bb = unitB ? std::min(Bb_target, Bt) : 0;
-    const size_t need = (size_t)Bt * per + (size_t)Bb * unitB_all + (1 << 20);
+    // (sample, level) pairs per unit-B sub-batch: no more than the call has
+    const int Bb = unitB ? (int)std::min<long long>(Bb_target, (long long)Bt * std::max(L, 1)) : 0;
+    const size_t need = (size_t)Bt * per + (size_t)Bb * unitB_all + dtmp_extra + (1 << 20);
     for (int i = 0; i < c->nstreams; ++i) arena_reserve(c, c->arenas[i], need);
 
     // internal MeanITE buffer when the caller did not ask for it but the draws need it
@@ -621,38 +625,43 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         }
 
         if (unitB) {
+            // Unit B batches over (posterior sample, level) PAIRS: a sub-batch is gs samples x lc levels (gs * lc <= Bb),
+            // batch element b = (sample b / lc, level l0 + b % lc).  Every pair has its own W / CovITE workspace; the
+            // factor of A and its inverted diagonal blocks are shared by a sample's levels (TRef::bdiv = lc) — the shape of
+            // predictCounterfactualEffects (src/prediction.jl:30-33): few samples, ~100 levels.
             double* Wt = ar.take<double>((size_t)Bb * nt * nt * GP_TSQ);
             double* Ct = ar.take<double>((size_t)Bb * nlow * GP_TSQ);
-            double* inv2 = ar.take<double>((size_t)Bb * nt * GP_TSQ);
-            // draws: the library's own normals of one level of the sub-batch (generated once per unit), and for a
-            // level sweep the staging buffer [b][l][d][i] that is rearranged into the level-fastest tensor at the end
+            const int lc_max = std::min(L, Bb);                   // levels per sub-batch
+            const int gs_max = std::max(1, Bb / lc_max);          // samples per sub-batch
+            // draws: the library's own normals of one sub-batch (generated once per unit), and for a level sweep the
+            // staging buffer [sample][level][d][i] that is rearranged into the level-fastest tensor sample group by group
             double* zgen = (want_draws && !io.z) ? ar.take<double>((size_t)Bb * io.spp * n) : nullptr;
-            double* dtmp = (want_draws && L > 1) ? ar.take<double>((size_t)Bb * L * io.spp * n) : nullptr;
+            double* dtmp = (want_draws && L > 1) ? ar.take<double>((size_t)gs_max * L * io.spp * n) : nullptr;
             const long long wbs = (long long)nt * nt * GP_TSQ, cbs = nlow * GP_TSQ;
-            std::vector<double> hdoT(L);
-            HC(hipMemcpyAsync(hdoT.data(), io.doT, sizeof(double) * L, hipMemcpyDeviceToHost, st));
-            HC(hipStreamSynchronize(st));
-            for (int u0 = 0; u0 < nb; u0 += Bb) {
-                const int ub = std::min(Bb, nb - u0);
-                for (int l = 0; l < L; ++l) {
+            for (int g0 = 0; g0 < nb; g0 += gs_max) {
+                const int gs = std::min(gs_max, nb - g0);
+                for (int l0 = 0; l0 < L; l0 += lc_max) {
+                    const int lc = std::min(lc_max, L - l0);
+                    const int ub = gs * lc;                           // (sample, level) pairs of this sub-batch
                     TRef W = rect_ref(Wt, wbs, nt);
                     TRef Cm = lower_ref(Ct, cbs);
-                    TRef Ls = lower_ref(tiles + (long long)u0 * bstride, bstride);
+                    TRef Ls = lower_ref(tiles + (long long)g0 * bstride, bstride);
+                    Ls.bdiv = lc;
                     DtArgs da{};
-                    da.X = io.X; da.T = c->dT; da.p = io.p; da.s0 = s0 + u0;
-                    da.n = n; da.nX = io.nX; da.nU = io.nU; da.nt = nt; da.doT = hdoT[l];
+                    da.X = io.X; da.T = c->dT; da.p = io.p; da.s0 = s0 + g0;
+                    da.n = n; da.nX = io.nX; da.nU = io.nU; da.nt = nt; da.doT = io.doT; da.l0 = l0; da.lc = lc;
                     da.pred_noise = io.pred_noise; da.W = W; da.Cm = Cm;
                     launch_dt_build(da, ub, st);
                     // W <- D L^-T, left-looking over tile columns; the panel product with inv(L_kk)^T is applied by the
                     // same work item that finishes the column update (the tile makes one HBM round trip, as in the
                     // factorisation), column 0 has no update and takes the panel product alone
-                    TRef invref = TRef{inv + (long long)u0 * inv_bs, inv_bs, 1, 0, 0, 0};
+                    TRef invref = TRef{inv + (long long)g0 * inv_bs, inv_bs, 1, 0, 0, 0};
+                    invref.bdiv = lc;
                     for (int k = 0; k < nt; ++k) {
                         GemmArgs g{};
                         g.A = W; g.C = W;
                         g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = nt; g.mj = 1; g.nbatch = ub; g.ntiles = nt;
-                        // fused up to a K depth of w_fuse_maxk tiles: beyond it the separate (HBM-bound) panel product is
-                        // a small share and the plain update kernel's higher MFMA rate wins (measured, profiles/)
+                        // fused up to a K depth of w_fuse_maxk tiles (measurement switch; +0.7 % fused at every depth)
                         static const int w_fuse_maxk = diag_env("GPSLC_FUSE_W_MAXK", 32);
                         if (k > 0 && k <= w_fuse_maxk && fuse_mode()) {
                             g.B = Ls; g.k0 = 0; g.k1 = k; g.accumulate = 1;
@@ -675,31 +684,31 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                         g.order = tri_order(c, nt);
                         gemm(c, g, st, 3);
                     }
-                    if (want_cov) {
+                    if (want_cov) {       // ITEDistributions: single level (lc == 1)
                         GatherCovArgs gc{};
-                        gc.Cm = Cm; gc.n = n; gc.nt = nt; gc.s0 = s0 + u0; gc.S = io.S; gc.out = io.CovITEs;
+                        gc.Cm = Cm; gc.n = n; gc.nt = nt; gc.s0 = s0 + g0; gc.S = io.S; gc.out = io.CovITEs;
                         launch_gather_cov(gc, ub, st);
                     }
                     if (want_draws) {
-                        potrf_tiles(c, Cm, nt, nt, inv2, inv_bs, io.info + s0 + u0, n, ub, st, 0, 3, /*robust=*/true);
+                        potrf_tiles(c, Cm, nt, nt, nullptr, 0, io.info + s0 + g0, n, ub, st, 0, 3, /*robust=*/true, /*info_div=*/lc);
                         DrawArgs dr{};
-                        dr.Lc = Cm; dr.n = n; dr.nt = nt; dr.s0 = s0 + u0; dr.S = io.S; dr.l = l; dr.L = L;
+                        dr.Lc = Cm; dr.n = n; dr.nt = nt; dr.s0 = s0 + g0; dr.S = io.S; dr.l = l0; dr.lc = lc; dr.L = L;
                         dr.spp = io.spp; dr.mean = meanITE; dr.z = io.z; dr.zgen = zgen; dr.seed = io.seed;
                         if (L == 1) {     // the reference tensor directly: n x (S*spp), instance fastest
                             dr.out = io.ite_draws;
-                            dr.obase = (long long)n * io.spp * (s0 + u0); dr.osb = (long long)n * io.spp;
+                            dr.obase = (long long)n * io.spp * (s0 + g0); dr.osb = (long long)n * io.spp; dr.osl = 0;
                             dr.osi = 1; dr.osd = n;
-                        } else {
+                        } else {          // staging [sample][level][d][i]
                             dr.out = dtmp;
-                            dr.obase = (long long)l * io.spp * n; dr.osb = (long long)L * io.spp * n;
-                            dr.osi = 1; dr.osd = n;
+                            dr.obase = (long long)l0 * io.spp * n; dr.osb = (long long)L * io.spp * n;
+                            dr.osl = (long long)io.spp * n; dr.osi = 1; dr.osd = n;
                         }
                         ProfScope ps(c, 2, (double)ub * io.spp, st);     // unit C: work = draws
                         launch_draws(dr, ub, st);
                     }
                 }
                 if (want_draws && L > 1)
-                    launch_draws_scatter(dtmp, io.ite_draws, n, L, io.spp, s0 + u0, ub, st);
+                    launch_draws_scatter(dtmp, io.ite_draws, n, L, io.spp, s0 + g0, gs, st);
             }
         }
     }

@@ -65,6 +65,7 @@ struct TRef {
     int kind;            // 0 = lower packed, 1 = rectangular
     int ro, co;          // tile offsets added to (i, j)
     int ld;              // tiles per tile-row (rectangular)
+    int bdiv;            // > 1: batch element b uses matrix b / bdiv (several (sample, level) units share one factor of A)
 };
 
 __host__ __device__ inline long long tref_index(const TRef& t, int i, int j) {
@@ -72,6 +73,7 @@ __host__ __device__ inline long long tref_index(const TRef& t, int i, int j) {
     return t.kind == 0 ? ii * (ii + 1) / 2 + jj : ii * (long long)t.ld + jj;
 }
 __host__ __device__ inline double* tref_tile(const TRef& t, long long b, int i, int j) {
+    if (t.bdiv > 1) b /= t.bdiv;
     return t.base + b * t.bstride + tref_index(t, i, j) * (long long)GP_TSQ;
 }
 
@@ -134,7 +136,7 @@ void launch_diag(const TRef& M, int k, double* inv, long long inv_bstride, int* 
                  int info_base, int nbatch, hipStream_t st);
 void launch_gram(const GramArgs& g, int nbatch, hipStream_t st);
 // substitution-based (backward-stable) diagonal-tile factorisation and panel solve for near-singular matrices (k_robust.hip)
-void launch_diag_robust(const TRef& M, int k, int* info, int info_base, int nbatch, hipStream_t st);
+void launch_diag_robust(const TRef& M, int k, int* info, int info_base, int nbatch, hipStream_t st, int info_div = 1);
 void launch_trsm_robust(const TRef& X, const TRef& L, int k, int i0, int count, int nbatch, hipStream_t st);
 
 struct RhsArgs {
@@ -179,7 +181,10 @@ void launch_process_cov(const double* in, long long n, double scale, double nois
 // unit B (full ITE covariance) helpers
 struct DtArgs {
     const double* X; const double* T; SampleParams p; long long s0;
-    int n, nX, nU, nt; double doT; double pred_noise;
+    int n, nX, nU, nt;
+    const double* doT;     // device: intervention levels; batch element b = (sample s0 + b / lc, level l0 + b % lc)
+    int l0, lc;
+    double pred_noise;
     TRef W;    // nt x nt rectangular: receives D (rows = i, cols = j), D_ij = B_ij (r_j - e_ij)
     TRef Cm;   // lower packed nt: receives Delta + pred_noise*I (identity on the padding)
 };
@@ -191,15 +196,17 @@ struct GatherCovArgs {
 void launch_gather_cov(const GatherCovArgs& a, int nbatch, hipStream_t st);
 
 struct DrawArgs {
-    TRef Lc; int n, nt; long long s0, S; int l, L, spp;
+    TRef Lc; int n, nt; long long s0, S; int l, L, spp;   // batch element b = (sample s0 + b / lc, level l + b % lc)
+    int lc;
     const double* mean;   // meanITE n x S x L
     const double* z;      // caller's normals, n x spp x S x L, or null
     double* zgen;         // z == null: workspace [nbatch][spp][n] the library's Philox normals are generated into
     unsigned long long seed;
-    // element (instance i, batch element b, draw d) of this launch's level goes to out[obase + b*osb + i*osi + d*osd]:
-    // the reference tensor L x n x (S*spp) directly (L == 1), or the level-sweep staging buffer [b][l][d][i]
+    // element (instance i, sample offset sb = b / lc, level offset lb = b % lc, draw d) of this launch goes to
+    // out[obase + sb*osb + lb*osl + i*osi + d*osd]: the reference tensor L x n x (S*spp) directly (L == 1), or the
+    // level-sweep staging buffer [sample][level][d][i]
     double* out;
-    long long obase, osb, osi, osd;
+    long long obase, osb, osl, osi, osd;
 };
 void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st);
 void launch_draws_scatter(const double* tmp, double* out, long long n, int L, int spp, long long s0, int nbatch,

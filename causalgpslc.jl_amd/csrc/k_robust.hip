@@ -26,7 +26,7 @@
 #define RB_NSB (GP_TS / SB)       // 8 sub-block rows / columns per tile
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void diag_potrf_robust_kernel(TRef M, int k, int* info, int info_base) {
+__global__ __launch_bounds__(256) void diag_potrf_robust_kernel(TRef M, int k, int* info, int info_base, int info_div) {
     extern __shared__ __attribute__((aligned(16))) double P[];        // 36 packed blocks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void diag_potrf_robust_kernel(TRef M, int k, i
         }
         __syncthreads();
     }
-    if (tid == 0 && bad != 0) atomicCAS(&info[b], 0, info_base + GP_TS * k + bad);
+    if (tid == 0 && bad != 0) atomicCAS(&info[b / info_div], 0, info_base + GP_TS * k + bad);   // info per posterior sample
     // factor back to the tile: lower blocks, zeros in the strictly-upper sub-blocks
     for (int bi = 0; bi < RB_NSB; ++bi)
         for (int bj = 0; bj < RB_NSB; ++bj)
@@ -175,11 +175,11 @@ __global__ __launch_bounds__(256) void tile_trsm_robust_kernel(TRef X, TRef L, i
     }
 }
 
-void launch_diag_robust(const TRef& M, int k, int* info, int info_base, int nbatch, hipStream_t st) {
+void launch_diag_robust(const TRef& M, int k, int* info, int info_base, int nbatch, hipStream_t st, int info_div) {
     const int bytes = 36 * 256 * 8;
     static DeviceOnce once;
     lds_opt_in(once, (const void*)diag_potrf_robust_kernel, bytes);
-    hipLaunchKernelGGL(diag_potrf_robust_kernel, dim3(nbatch), dim3(256), bytes, st, M, k, info, info_base);
+    hipLaunchKernelGGL(diag_potrf_robust_kernel, dim3(nbatch), dim3(256), bytes, st, M, k, info, info_base, info_div < 1 ? 1 : info_div);
 }
 
 // X(i, k) <- X(i, k) L_kk^-T for the tiles i = i0 .. i0 + count - 1 of tile column k of X (X may be the factor's own

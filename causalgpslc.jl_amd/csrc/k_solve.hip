@@ -447,7 +447,8 @@ __global__ __launch_bounds__(256) void dt_build_kernel(DtArgs a) {
     double* rc_ = rr_ + GP_TS;  // r_j of the column block
     const int tid = threadIdx.x;
     const int ti = blockIdx.x / a.nt, tj = blockIdx.x % a.nt;
-    const long long b = blockIdx.y, s = a.s0 + b;
+    const long long b = blockIdx.y, s = a.s0 + b / a.lc;       // batch element = (sample, level) pair
+    const double doT = a.doT[a.l0 + (int)(b % a.lc)];
     const int n = a.n;
     const int gi0 = ti * GP_TS, gj0 = tj * GP_TS;
     const double tl = a.p.tyLS[s];
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(256) void dt_build_kernel(DtArgs a) {
         const double t1 = (gi0 + tid < n) ? a.T[gi0 + tid] : 0.0;
         const double t2 = (gj0 + tid < n) ? a.T[gj0 + tid] : 0.0;
         tr[tid] = t1; tc[tid] = t2;
-        const double d1 = t1 - a.doT, d2 = t2 - a.doT;
+        const double d1 = t1 - doT, d2 = t2 - doT;
         rr_[tid] = gp_exp_neg(-((d1 * d1) * wt));
         rc_[tid] = gp_exp_neg(-((d2 * d2) * wt));
     }
@@ -579,10 +580,10 @@ __device__ __forceinline__ double philox_normal(unsigned long long seed, unsigne
 // workspace laid out like the caller-supplied form (z[g + n*d] per unit): thread = one Philox counter = the
 // pair of elements (2p, 2p + 1) -> (cos, sin) branch of one Box-Muller transform, exactly the values
 // philox_normal() returns for those two elements.
-__global__ __launch_bounds__(256) void normals_kernel(unsigned long long seed, long long s0, long long S, int l,
+__global__ __launch_bounds__(256) void normals_kernel(unsigned long long seed, long long s0, long long S, int l, int lc,
                                                       long long n, int spp, double* out) {
-    const long long b = blockIdx.y;
-    const unsigned long long stream = (unsigned long long)(s0 + b + S * (long long)l);
+    const long long b = blockIdx.y;             // (sample s0 + b / lc, level l + b % lc)
+    const unsigned long long stream = (unsigned long long)(s0 + b / lc + S * (long long)(l + b % lc));
     const long long total = n * spp;                       // elements of this unit
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (2 * p >= total) return;
@@ -609,9 +610,10 @@ __global__ __launch_bounds__(256) void draws_mfma_kernel(DrawArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int ib = a.nt - 1 - (int)blockIdx.x;          // longest tile rows first
-    const long long b = blockIdx.y, s = a.s0 + b;
+    const long long b = blockIdx.y, sb = b / a.lc, lb = b % a.lc;      // batch element = (sample, level) pair
+    const long long s = a.s0 + sb, lev = a.l + lb;
     const long long n = a.n;
-    const double* __restrict__ zu = a.z ? a.z + n * a.spp * (s + a.S * (long long)a.l) : a.zgen + n * a.spp * b;
+    const double* __restrict__ zu = a.z ? a.z + n * a.spp * (s + a.S * lev) : a.zgen + n * a.spp * b;
     const int r0 = 32 * wave + 2 * li;                  // this lane's two rows inside the tile: r0, r0 + 1
     const long long gi = (long long)ib * GP_TS + r0;
 
@@ -660,9 +662,9 @@ __global__ __launch_bounds__(256) void draws_mfma_kernel(DrawArgs a) {
         }
         // acc[m][q][v]: row r0 + m, draw d0 + 16 q + 4 v + lq
         if (gi < n) {
-            const double mu0 = a.mean[gi + n * (s + a.S * (long long)a.l)];
-            const double mu1 = (gi + 1 < n) ? a.mean[gi + 1 + n * (s + a.S * (long long)a.l)] : 0.0;
-            double* __restrict__ ob = a.out + a.obase + b * a.osb + gi * a.osi;
+            const double mu0 = a.mean[gi + n * (s + a.S * lev)];
+            const double mu1 = (gi + 1 < n) ? a.mean[gi + 1 + n * (s + a.S * lev)] : 0.0;
+            double* __restrict__ ob = a.out + a.obase + sb * a.osb + lb * a.osl + gi * a.osi;
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -723,7 +725,7 @@ void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st) {
     if (!a.z) {     // the library's own stream: every normal of the unit is generated exactly once
         const long long pairs = ((long long)a.n * a.spp + 1) / 2;
         hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((pairs + 255) / 256), nbatch), dim3(256), 0, st, a.seed, a.s0,
-                           a.S, a.l, (long long)a.n, a.spp, a.zgen);
+                           a.S, a.l, a.lc, (long long)a.n, a.spp, a.zgen);
     }
     if (a.spp <= 16) launch_draws_t<1>(a, nbatch, st);
     else if (a.spp <= 32) launch_draws_t<2>(a, nbatch, st);

@@ -210,6 +210,27 @@ def test_draws_all_per_unit_in_one_pass_and_level_sweep_layout(gp, spp, L):
     assert np.allclose(dr_p, dr_z, rtol=0, atol=1e-9 * max(1.0, np.max(np.abs(dr_z))))
 
 
+def test_draws_pair_batching_more_levels_than_a_sub_batch(gp):
+    """Unit B batches over (sample, level) pairs; a sweep with more levels than one sub-batch holds (150 > 128 at this
+    size) is cut into level chunks per sample, a short one into several samples per sub-batch.  Both against the literal
+    restatement with the caller's normals (jitter 1e-3), every level."""
+    n, S, spp = 40, 3, 2
+    c = cases.make_case(n, "UX", False, S=S, seed=321)
+    pn = 1e-3
+    obj = cases.gpslc_object(gp, c, hyperparams=gp.HyperParameters(predictionCovarianceNoise=pn))
+    smp = cases.samples_of(c)
+    for L in (150, 5):
+        doTs = np.linspace(-1.0, 1.2, L)
+        z = np.random.default_rng(L).standard_normal((n, spp, S, L))
+        _, _, _, dr = gp.predict(obj, doTs, spp=spp, z=z, want_draws=True)
+        assert dr.shape == (L, n, S * spp)
+        for l in range(L):
+            M, Cv = orc.ite_distributions(smp, c["X"], c["T"], c["Y"], float(doTs[l]), pn)
+            zl = np.asfortranarray(z[:, :, :, l]).reshape(n, spp * S, order="F")
+            ref = orc.ite_samples(M, Cv, spp, zl)
+            assert np.max(np.abs(dr[l] - ref)) <= 1e-8 * np.max(np.abs(ref)) + 1e-12, l
+
+
 def test_predict_counterfactual_effects_shape_and_levels(gp):
     # test/prediction.jl:1-13 (shape / plumbing) + level sweep consistency with sampleITE
     c = cases.make_case(40, "UX", False, S=3, seed=77)
