@@ -123,6 +123,33 @@ def test_unit_b_with_draws_n1024_default_jitter(gp):
             assert np.linalg.norm(out[:, col] - ref[:, col]) <= 1e-8 * lc_norm * np.linalg.norm(z[:, col])
 
 
+def test_unit_b_pairs_and_robust_factor_n2048(gp):
+    """Full ITE covariance + its factor + draws across 16 x 16 tiles: 2 posterior samples x 2 levels in one sub-batch
+    ((sample, level) pair batching), CovITE + 1e-6 I factorised by the substitution-based tiled Cholesky, draws with the
+    caller's normals against numpy's Cholesky of the structured oracle's CovITE, every pair."""
+    n, D, K, S, L, spp = 2048, 8, 2, 2, 2, 1
+    X, T, Y, objid = gp.synth.make_dataset(n, D)
+    post = gp.synth.make_posterior(n, D, K, S, objid)
+    pn = 1e-6
+    g = gp.GPSLCObject(X, T, Y, post["U"], post["uyLS"], post["xyLS"], post["tyLS"], post["yNoise"], post["yScale"],
+                       hyperparams=gp.HyperParameters(predictionCovarianceNoise=pn))
+    doTs = gp.synth.levels(T, L)
+    z = np.random.default_rng(9).standard_normal((n, spp, S, L))
+    _, _, mi, dr = gp.predict(g, doTs, want_mean_ite=True, spp=spp, z=z, want_draws=True)
+    assert not g.ctx().last_info(S).any()
+    for s in range(S):
+        p = _sample(post, s, D, K)
+        for l in range(L):
+            m, cov = orc.structured_ite(p, X, T, Y, float(doTs[l]))
+            cov = (cov + cov.T) / 2 + pn * np.eye(n)
+            ev = np.linalg.eigvalsh(cov)
+            Lc = np.linalg.cholesky(cov)
+            ref = m + Lc @ z[:, 0, s, l]
+            bound = max(1e-8, 1e-15 * ev[-1] / ev[0]) * np.sqrt(ev[-1]) * np.linalg.norm(z[:, 0, s, l])
+            assert np.linalg.norm(dr[l][:, s * spp] - ref) <= bound + 1e-9 * np.linalg.norm(ref), (s, l)
+            assert np.max(np.abs(mi[:, s, l] - m)) <= 1e-8 * np.max(np.abs(m)) + 1e-12
+
+
 def test_permutation_invariance_n1024(gp):
     n, D, K, S = 1024, 4, 1, 6
     g, (X, T, Y, post) = _obj(gp, n, D, K, S, seed=77)
