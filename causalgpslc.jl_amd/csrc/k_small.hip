@@ -65,26 +65,56 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
     __syncthreads();
     const unsigned long long t0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
 
-    // ---- Gram build into the packed blocks (src/kernel.jl:13-32, 53-59): one block per wave and iteration, four
-    // independent entries per lane (the exp chains of a wave would otherwise run back to back)
+    // ---- Gram build into the packed blocks (src/kernel.jl:13-32, 53-59): two blocks per wave and iteration = eight
+    // independent entries per lane, the feature loop outermost, so that eight distance accumulations and then eight exp
+    // chains interleave (a wave's dependent chains would otherwise run back to back: one or two waves per SIMD here)
     {
         int bi = 0, bj = 0;                              // block `wave` of the row-major lower-triangle enumeration
         for (int t = 0; t < wave; ++t) { if (++bj > bi) { ++bi; bj = 0; } }
-        for (int blk = wave; blk < NBLK; blk += SM_WAVES) {
-            double v[4];
+        for (int blk = wave; blk < NBLK; blk += 2 * SM_WAVES) {
+            int bi2 = bi, bj2 = bj;                      // the second block of this iteration: blk + SM_WAVES
+            for (int t = 0; t < SM_WAVES; ++t) { if (++bj2 > bi2) { ++bi2; bj2 = 0; } }
+            const bool two = blk + SM_WAVES < NBLK;
+            int gi[8], gj[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int w = lane + 64 * u;
-                const int i = SB * bi + (w & 15), j = SB * bj + (w >> 4);
-                if (nd.cov)        // dense covariance node (uCov = SigmaU * uNoise, src/model_likelihood.jl:4-10)
-                    v[u] = (i < n && j < n) ? nd.covscale * nd.cov[(long long)j * n + i] : (i == j ? 1.0 : 0.0);
-                else
-                    v[u] = sm_gram_entry(fs, NP, nd.nF, n, i, j, nd.scale, nd.noise);
+            for (int u = 0; u < 8; ++u) {
+                const int w = lane + 64 * (u & 3);
+                gi[u] = SB * (u < 4 ? bi : bi2) + (w & 15);
+                gj[u] = SB * (u < 4 ? bj : bj2) + (w >> 4);
+            }
+            double v[8];
+            if (nd.cov) {          // dense covariance node (uCov = SigmaU * uNoise, src/model_likelihood.jl:4-10)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = (gi[u] < n && gj[u] < n && (u < 4 || two)) ? nd.covscale * nd.cov[(long long)gj[u] * n + gi[u]]
+                                                                       : (gi[u] == gj[u] ? 1.0 : 0.0);
+            } else {
+                double lux[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) lux[u] = 0.0;
+                for (int f = 0; f < nd.nF; ++f) {
+                    const double* ff = fs + f * NP;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double d = ff[gi[u]] - ff[gj[u]];      // padded instances carry zeros: harmless, masked below
+                        lux[u] = fma(d, d, lux[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double e = nd.scale * gp_exp_neg(-lux[u]);
+                    v[u] = (gi[u] < n && gj[u] < n) ? (gi[u] == gj[u] ? e + nd.noise : e) : (gi[u] == gj[u] ? 1.0 : 0.0);
+                }
             }
             double* B = P + (blk << 8);
 #pragma unroll
             for (int u = 0; u < 4; ++u) B[lane + 64 * u] = v[u];
-            for (int t = 0; t < SM_WAVES; ++t) { if (++bj > bi) { ++bi; bj = 0; } }
+            if (two) {
+                double* B2 = P + ((blk + SM_WAVES) << 8);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) B2[lane + 64 * u] = v[4 + u];
+            }
+            for (int t = 0; t < 2 * SM_WAVES; ++t) { if (++bj > bi) { ++bi; bj = 0; } }
         }
     }
     int bad = 0;
