@@ -31,7 +31,20 @@ for n, F in ((150, 2), (150, 8), (160, 3), (272, 8), (400, 8), (640, 8), (641, 8
     for _ in range(reps):
         gp.nodesLogpdf(nodes, ctx)
     dt3 = (time.perf_counter() - t0) / reps
-    print(f"n={n} F={F}: gpLogpdf {dt * 1e6:.0f} us per score; fused 3-node call {dt3 * 1e6:.0f} us", flush=True)
+    # the C entry point alone (arrays marshalled once): what a Julia ccall would see
+    import ctypes as C
+    sc, no, out = np.array([1.3]), np.array([0.4]), np.empty(1)
+    Ff, lsf = np.asfortranarray(Fm), np.ascontiguousarray(ls)
+    args = (ctx.h, 1, F, Ff.ctypes.data_as(C.c_void_p), 1, lsf.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+            no.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p))
+    fn = ctx.lib.gpslc_gp_logpdf
+    fn(*args)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn(*args)
+    dtc = (time.perf_counter() - t0) / reps
+    print(f"n={n} F={F}: gpLogpdf {dt * 1e6:.0f} us per score ({dtc * 1e6:.0f} us for the C call alone); "
+          f"fused 3-node call {dt3 * 1e6:.0f} us", flush=True)
 
 neec = os.path.join(ROOT, "tests", "golden", "neec", "NEEC_sampled.csv")
 gp.gpslc(neec, seed=1)
