@@ -136,9 +136,12 @@ int gpslc_nodes_logpdf(gpslc_ctx* ctx, int32_t count, const gpslc_node* nodes, d
 
 /* log N(x_s; 0, covscale_s * cov) for S vectors and one dense n x n covariance: the :U => u => :U nodes
  * (generateUfromSigmaU, src/model_likelihood.jl:4-10 with uCov = SigmaU * uNoise; generateU,
- * src/model_prior.jl:27-30).  A non-NULL cov is factorised and the factor cached in the ctx (SigmaU is
- * constant for a data set); cov = NULL re-uses the cached factor, so one evaluation costs a tiled
- * forward solve only.  S = 0 with a non-NULL cov just (re)factorises.  covscale may be NULL (= 1). */
+ * src/model_prior.jl:27-30).  A non-NULL cov is handed over and cached in the ctx (SigmaU is constant for a data
+ * set) — as the matrix itself for n <= 640 (every evaluation scales and factorises it inside one workgroup), as its
+ * tiled factor beyond; cov = NULL re-uses it.  S = 0 with a non-NULL cov just hands over and validates (returns the
+ * failing pivot if cov is not positive definite).  covscale may be NULL (= 1).  SigmaU is positive definite only by
+ * its 1e-13 jitter (src/utils.jl:17-33): every factorisation and solve here is substitution-based (no products with
+ * inverted blocks), i.e. backward stable like LAPACK's potrf / trsm. */
 int gpslc_mvn_logpdf(gpslc_ctx* ctx, int64_t S, const double* cov, const double* covscale /* S */,
                      const double* x /* n x S */, double* logpdf /* S */);
 
