@@ -118,3 +118,23 @@ def test_dense_covariance_nodes_small_path(gp):
     with pytest.raises(gp.PosDefException) as ei:
         gp.mvnLogpdf(bad, Uk[:, :0].reshape(n, 0), ctx=ctx)
     assert ei.value.info == 71
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sizes_and_feature_counts(gp, seed):
+    """Randomised shapes across the LDS-resident (n <= 176) and left-looking (n <= 640) kernels: every block-count /
+    padding / wave-assignment combination a fixed grid of sizes would miss."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(1, 330)) if seed % 3 else int(rng.integers(330, 641))
+    ctx = gp.Context(n, 0, 0)
+    nodes = []
+    for _ in range(int(rng.integers(1, 6))):
+        nF = int(rng.integers(0, 13))
+        F = None if nF == 0 else rng.standard_normal((n, nF)) * rng.uniform(0.5, 2.0)
+        ls = None if nF == 0 else rng.uniform(0.5, 3.0, nF)
+        nodes.append((F, ls, rng.uniform(0.3, 3.0), rng.uniform(0.2, 2.0), rng.standard_normal(n) * rng.uniform(0.1, 10.0)))
+    out = gp.nodesLogpdf(nodes, ctx)
+    ref = np.array([_ref(*q) for q in nodes])
+    assert np.allclose(out, ref, rtol=1e-10, atol=1e-9), (n, out, ref)
+    again = gp.nodesLogpdf(nodes, ctx)
+    assert np.array_equal(out, again)          # deterministic: no race in the LDS / scratch hand-overs
