@@ -60,3 +60,25 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgpslc_hip.so")
     with pytest.raises(_lib.GPSLCLibraryError):
         _lib.load()
+
+
+def test_struct_layouts_match_the_c_header(tmp_path):
+    """gpslc_node and gpslc_pack_header as ctypes declares them vs. what a C compiler makes of include/gpslc_hip.h
+    (size and every field offset): the layout a Julia `struct` / any other FFI has to reproduce."""
+    import subprocess
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "gpslc_hip.h"\n'
+        'int main(void) {\n'
+        '  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(gpslc_node), offsetof(gpslc_node, nF), offsetof(gpslc_node, F),\n'
+        '         offsetof(gpslc_node, ls), offsetof(gpslc_node, scale), offsetof(gpslc_node, noise), offsetof(gpslc_node, target));\n'
+        '  printf("%zu %zu %zu %zu\\n", sizeof(gpslc_pack_header), offsetof(gpslc_pack_header, S),\n'
+        '         offsetof(gpslc_pack_header, binary_t), offsetof(gpslc_pack_header, hyper));\n'
+        '  return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.dirname(_lib.HEADER_PATH), str(src), "-o", str(exe)], check=True)
+    node, pack = [tuple(int(v) for v in line.split()) for line in
+                  subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()]
+    N, P = _lib.Node, _lib.PackHeader
+    assert node == (ctypes.sizeof(N), N.nF.offset, N.F.offset, N.ls.offset, N.scale.offset, N.noise.offset, N.target.offset)
+    assert pack == (ctypes.sizeof(P), P.S.offset, P.binary_t.offset, P.hyper.offset)

@@ -145,3 +145,17 @@ def test_production_library_ignores_measurement_switches():
     inst = sorted(set(l.split("tile_gemm_nt_kernel")[1].split("(")[0] for l in syms.splitlines()
                       if "__device_stub__tile_gemm_nt_kernel" in l))
     assert all(i.split(",")[1].strip() == "0" for i in inst), inst     # no timing-only (DIAG != 0) instantiation
+
+
+def test_plain_c_consumer(tmp_path):
+    """The ABI consumed from plain C (tests/c/abi_consumer.c, compiled with gcc against include/gpslc_hip.h and linked
+    to libgpslc_hip.so): closed-form node scores at n = 150 (LDS-resident kernel), 272 (left-looking kernel) and 700
+    (tiled path), the fused node call, an argument error and a not-positive-definite matrix."""
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "causalgpslc.jl_amd", "csrc")
+    exe = str(tmp_path / "abi_consumer")
+    subprocess.run(["gcc", "-std=c99", "-O1", "-I", inc, os.path.join(ROOT, "tests", "c", "abi_consumer.c"), "-o", exe,
+                    "-L", libdir, "-lgpslc_hip", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
+    assert "gfx950" in r.stdout and r.stdout.strip().endswith("ok")
