@@ -843,7 +843,8 @@ int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* l
         nF_max = std::max(nF_max, nodes[i].nF);
     }
     const size_t off_out = ((size_t)count * sizeof(SmallNode) + 63) & ~size_t(63);
-    const size_t off_data = off_out + (size_t)count * 12 * sizeof(double);     // 4 results + 8 stamp words per node
+    // 4 results + 8 stamp words per node (+ 8 x 8 per-wave words of node 0 for the mid-size kernel: measurement build)
+    const size_t off_data = off_out + ((size_t)count * 12 + 64) * sizeof(double);
     pin_reserve(c, off_data + doubles * sizeof(double));
     void* dbase = nullptr;
     HC(hipHostGetDevicePointer(&dbase, c->pin, 0));
@@ -902,6 +903,14 @@ int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* l
         if (printed++ < want_stamps)
             fprintf(stderr, "small_gp stamps (shader clocks): inputs %.0f gram %.0f factor+panel %.0f update %.0f total %.0f\n",
                     sp[0], sp[1], sp[2], sp[3], sp[5]);
+    }
+    if (want_stamps && !in_lds) {      // node 0, per wave: cumulative shader clocks of the phases over all block columns
+        static int printed = 0;
+        const double* sp = hout + 12 * (size_t)count;
+        if (printed++ < want_stamps)
+            for (int w = 0; w < 8; ++w)
+                fprintf(stderr, "mid_gp wave %d: gram %.0f k-loop %.0f to-LDS %.0f wait %.0f factor+store %.0f wait %.0f\n", w,
+                        sp[8 * w], sp[8 * w + 1], sp[8 * w + 2], sp[8 * w + 3], sp[8 * w + 4], sp[8 * w + 5]);
     }
 #endif
     const double l2pi = 1.8378770664093454835606594728112;

@@ -28,7 +28,8 @@
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void diag_potrf_robust_kernel(TRef M, int k, int* info, int info_base, int info_div) {
     extern __shared__ __attribute__((aligned(16))) double P[];        // 36 packed blocks
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: branches on it are scalar branches
     const int li = lane & 15;
     const long long b = blockIdx.x;
     double* tile = tref_tile(M, b, k, k);
@@ -105,7 +106,8 @@ __device__ __forceinline__ void rb_solve_rows(double (&r)[SB], bool is_diag) {
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_trsm_robust_kernel(TRef X, TRef L, int k, int i0) {
     extern __shared__ __attribute__((aligned(16))) double XB[];      // [rb 8][cb 8] blocks of 256 doubles: the tile (i, k)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: branches on it are scalar branches
     const int li = lane & 15, lg = lane >> 4;
     const long long b = blockIdx.y;
     const int i = i0 + blockIdx.x;

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
     double* zv = yv + NP;             // z = L^-1 target
     double* ldv = zv + NP;            // diag(L), for the log-determinant
     double* fs = ldv + NP;            // scaled features, fs[f*NP + i] = F[i, f] * (1 / ls[f]) (scaled by the host)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: branches on it are scalar branches
     const int li = lane & 15;
 
     for (int idx = tid; idx < nd.nF * NP; idx += SM_THREADS) {
@@ -234,138 +235,214 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
 // The right-hand side rides along as block row NB (its row 0 = target, the other 15 rows zero): z = L^-1 target
 // falls out of the same block operations, no special case.  Three barriers per block column.
 // ---------------------------------------------------------------------------------------------------------------------
-#define MID_MAXI 6         // block rows per wave: (NB + 1) <= 8 * MID_MAXI  ->  NB <= 47, limited to n <= 640 by the host
+#define MID_MAXI 6         // block rows per wave at most: (NB + 1) <= 8 * MID_MAXI  ->  NB <= 47, limited to n <= 640 by the host
 #define MBLK(i, j) (X + ((((long long)(i) * ((i) + 1)) / 2 + (j)) << 8))     // scratch: packed lower blocks, rows 0..NB
 
+// operand-fragment register sets of the k loop for a wave that owns R block rows: the fragments of steps
+// k+1 .. k+NSET-1 are in flight (L2 latency ~ 1000 cycles) while the MFMAs of step k (256 cycles per block row) run;
+// a set is 8 (1 + R) VGPRs
+__host__ __device__ constexpr int mid_nset(int R) { return R <= 1 ? 6 : R == 2 ? 5 : R == 3 ? 4 : R == 4 ? 3 : 2; }
+
+struct MidCtx {
+    const double* X;        // scratch: finished block columns
+    double* Cp;             // LDS image of the current block column
+    const double* fl;       // LDS features (FL: [f][NP]; else the block column's [f][16])
+    const double* featg;    // !FL: features in the scratch [f][NP]
+    const double* tgt;      // right-hand side [NP]
+    int n, NB, NP, p, wave, lane;
+#ifdef GPSLC_DIAG
+    long long* tt;          // per-wave phase clocks (measurement build)
+#endif
+};
+#ifdef GPSLC_DIAG
+#define MID_STAMP(tt, j) do { const long long now_ = __builtin_amdgcn_s_memtime(); (tt)[j] += now_ - (tt)[7]; (tt)[7] = now_; } while (0)
+#else
+#define MID_STAMP(tt, j) do { } while (0)
+#endif
+
+// accumulate phase of block column p for a wave that owns EXACTLY R block rows i = p + wave + 8u, u < R (the last one
+// may be the right-hand side row NB).  R is a template parameter and `wave` a scalar, so the body is straight-line
+// code: the compiler counts the outstanding loads exactly (s_waitcnt vmcnt(N)) and the prefetch ring really overlaps.
+template <int R, bool FL>
+__device__ __forceinline__ void mid_accumulate(const SmallNode& nd, const MidCtx& c) {
+    constexpr int NSET = mid_nset(R);
+    const double* X = c.X;
+    const int p = c.p, lane = c.lane, li = lane & 15, lg = lane >> 4, NP = c.NP, NB = c.NB, n = c.n;
+    const int i0 = p + c.wave;
+    const bool last_rhs = (i0 + SM_WAVES * (R - 1) == NB);       // scalar
+    d4 acc[R];
+    // Gram blocks (i, p) of all the wave's rows together: element (row 16i + li, col 16p + lg + 4v); the feature loop is
+    // the outer one: 4 R independent distance / exp chains in flight.  The right-hand side row computes a throw-away
+    // block on the last real block row's features.
+    {
+        double lux[R][4];
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) lux[u][v] = 0.0;
+        if (!nd.cov) {
+            for (int f = 0; f < nd.nF; ++f) {
+                double cf[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cf[v] = FL ? c.fl[f * NP + SB * p + lg + 4 * v] : c.fl[f * SB + lg + 4 * v];
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const int i = min(i0 + SM_WAVES * u, NB - 1);
+                    const double xr = FL ? c.fl[f * NP + SB * i + li] : c.featg[f * NP + SB * i + li];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const double d = xr - cf[v];
+                        lux[u][v] = fma(d, d, lux[u][v]);
+                    }
+                }
+            }
+        }
+        if (nd.cov) {        // dense covariance handed over by the caller (scalar branch: one code path per node)
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int gi = SB * min(i0 + SM_WAVES * u, NB - 1) + li;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int gj = SB * p + lg + 4 * v;
+                    const bool in = gi < n && gj < n;
+                    const double cv = nd.cov[in ? (long long)gj * n + gi : 0];
+                    acc[u][v] = in ? nd.covscale * cv : (gi == gj ? 1.0 : 0.0);
+                }
+            }
+        } else {             // branch-free: the exp chains of all 4 R entries interleave
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int gi = SB * min(i0 + SM_WAVES * u, NB - 1) + li;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int gj = SB * p + lg + 4 * v;
+                    const double e = nd.scale * gp_exp_neg(-lux[u][v]) + (gi == gj ? nd.noise : 0.0);
+                    acc[u][v] = (gi < n && gj < n) ? e : (gi == gj ? 1.0 : 0.0);
+                }
+            }
+        }
+        if (last_rhs) {      // right-hand side block: row 0 = target
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[R - 1][v] = (li == 0) ? c.tgt[SB * p + lg + 4 * v] : 0.0;
+        }
+    }
+    MID_STAMP(c.tt, 0);
+    // k loop: a ring of NSET operand sets, unrolled by NSET so that the set indices are static
+    double fj[NSET][4], fi[NSET][R][4];
+    auto fetch = [&](int k, double (&fjs)[4], double (&fis)[R][4]) {
+        const double* Xpk = MBLK(p, k);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fjs[kk] = sm_frag(Xpk, kk, lane);
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const double* Xik = MBLK(i0 + SM_WAVES * u, k);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fis[u][kk] = sm_frag(Xik, kk, lane);
+        }
+    };
+    auto apply = [&](const double (&fjs)[4], const double (&fis)[R][4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int u = 0; u < R; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fjs[kk], fis[u][kk], acc[u], 0, 0, 1);
+    };
+#pragma unroll
+    for (int s = 0; s < NSET - 1; ++s)
+        if (s < p) fetch(s, fj[s], fi[s]);
+    for (int k0 = 0; k0 < p; k0 += NSET) {
+#pragma unroll
+        for (int s = 0; s < NSET; ++s) {
+            const int k = k0 + s;
+            if (k < p) {
+                if (k + NSET - 1 < p) fetch(k + NSET - 1, fj[(s + NSET - 1) % NSET], fi[(s + NSET - 1) % NSET]);
+                apply(fj[s], fi[s]);
+            }
+        }
+    }
+    MID_STAMP(c.tt, 1);
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        double* B = c.Cp + ((c.wave + SM_WAVES * u) << 8);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) B[(lg + 4 * v) * SB + li] = acc[u][v];
+    }
+}
+
+// FL    scaled features + target resident in LDS for the whole kernel (they fit for every size the reference uses);
+//       otherwise they sit in the scratch and the 16 instances of the current block column are staged per column
+template <bool FL>
 __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) double P[];
     const SmallNode nd = blockIdx.x < SMALL_INLINE_NODES ? a.inl[blockIdx.x] : a.nodes[blockIdx.x];
     const int n = a.n, NB = a.NB, NP = NB * SB, NBa = NB + 1;
     double* __restrict__ X = a.scratch + (long long)blockIdx.x * a.scratch_stride;     // finished columns
-    double* feat = X + ((long long)NBa * (NBa + 1) / 2) * 256;                           // scaled features [f][NP]
     double* Cp = P;                       // current block column: slot (i - p) = block (i, p), i = p..NB
     double* ldv = Cp + NBa * 256;         // diag(L)
-    double* fsp = ldv + NP;               // features of the 16 instances of block column p: fsp[f*16 + c]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lg = lane >> 4;
+    double* fl = ldv + NP;                // FL: features [f][NP] then target [NP];  else: the block column's features [f][16]
+    double* featg = X + ((long long)NBa * (NBa + 1) / 2) * 256;                        // !FL: features [f][NP], target [NP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: every branch on it is a scalar branch
+    const int li = lane & 15;
 
-    for (int idx = tid; idx < nd.nF * NP; idx += SM_THREADS) {
-        const int f = idx / NP, i = idx - f * NP;
-        feat[idx] = (i < n) ? nd.Fs[(long long)f * n + i] : 0.0;
+    {
+        double* dstf = FL ? fl : featg;
+        for (int idx = tid; idx < nd.nF * NP; idx += SM_THREADS) {
+            const int f = idx / NP, i = idx - f * NP;
+            dstf[idx] = (i < n) ? nd.Fs[(long long)f * n + i] : 0.0;
+        }
+        // the right-hand side too: it is read once per block column, and nd.target lives in pinned HOST memory
+        double* dstt = dstf + (long long)nd.nF * NP;
+        for (int i = tid; i < NP; i += SM_THREADS) dstt[i] = (i < n) ? nd.target[i] : 0.0;
     }
-    // the right-hand side too: it is read once per block column, and nd.target lives in pinned HOST memory
-    double* tgt = feat + (long long)nd.nF * NP;
-    for (int i = tid; i < NP; i += SM_THREADS) tgt[i] = (i < n) ? nd.target[i] : 0.0;
+    MidCtx mc;
+    mc.X = X; mc.Cp = Cp; mc.fl = fl; mc.featg = featg; mc.tgt = (FL ? fl : featg) + (long long)nd.nF * NP;
+    mc.n = n; mc.NB = NB; mc.NP = NP; mc.wave = wave; mc.lane = lane;
+#ifdef GPSLC_DIAG
+    long long tt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    mc.tt = tt;
+#endif
     __threadfence_block();
     __syncthreads();
     int bad = 0;
+#ifdef GPSLC_DIAG
+    tt[7] = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int p = 0; p < NB; ++p) {
-        for (int idx = tid; idx < nd.nF * SB; idx += SM_THREADS) fsp[idx] = feat[(idx >> 4) * NP + SB * p + (idx & 15)];
-        __syncthreads();
-        // ---- accumulate: block rows i = p + wave + 8u
-        {
-            d4 acc[MID_MAXI];
-#pragma unroll
-            for (int u = 0; u < MID_MAXI; ++u) {
-                const int i = p + wave + SM_WAVES * u;
-                acc[u] = (d4){0.0, 0.0, 0.0, 0.0};
-                if (i < NB) {             // Gram block (i, p): element (row 16i + li, col 16p + lg + 4v)
-                    const int gi = SB * i + li;
-                    double lux[4] = {0.0, 0.0, 0.0, 0.0};
-                    for (int f = 0; f < nd.nF; ++f) {
-                        const double xr = feat[f * NP + gi];
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const double d = xr - fsp[f * SB + lg + 4 * v];
-                            lux[v] = fma(d, d, lux[v]);
-                        }
-                    }
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int gj = SB * p + lg + 4 * v;
-                        double val;
-                        if (gi < n && gj < n) {
-                            if (nd.cov) val = nd.covscale * nd.cov[(long long)gj * n + gi];
-                            else {
-                                val = nd.scale * gp_exp_neg(-lux[v]);
-                                if (gi == gj) val += nd.noise;
-                            }
-                        } else {
-                            val = (gi == gj) ? 1.0 : 0.0;
-                        }
-                        acc[u][v] = val;
-                    }
-                } else if (i == NB) {     // right-hand side block: row 0 = target
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int gj = SB * p + lg + 4 * v;
-                        acc[u][v] = (li == 0) ? tgt[gj] : 0.0;
-                    }
-                }
-            }
-            // k loop, software-pipelined by hand: the fragments of step k+1 are in flight (L2 latency ~1 us) while the
-            // MFMAs of step k run; two register sets, loop unrolled by two so that their indices are static
-            double fj0[4], fj1[4], fi0[MID_MAXI][4], fi1[MID_MAXI][4];
-            auto fetch = [&](int k, double (&fj)[4], double (&fi)[MID_MAXI][4]) {
-                const double* Xpk = MBLK(p, k);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) fj[kk] = sm_frag(Xpk, kk, lane);
-#pragma unroll
-                for (int u = 0; u < MID_MAXI; ++u) {
-                    const int i = p + wave + SM_WAVES * u;
-                    if (i <= NB) {
-                        const double* Xik = MBLK(i, k);
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) fi[u][kk] = sm_frag(Xik, kk, lane);
-                    }
-                }
-            };
-            auto apply = [&](const double (&fj)[4], const double (&fi)[MID_MAXI][4]) {
-#pragma unroll
-                for (int u = 0; u < MID_MAXI; ++u) {
-                    const int i = p + wave + SM_WAVES * u;
-                    if (i <= NB) {
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-                            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[kk], fi[u][kk], acc[u], 0, 0, 1);
-                    }
-                }
-            };
-            if (p > 0) fetch(0, fj0, fi0);
-            for (int k = 0; k < p; k += 2) {
-                if (k + 1 < p) fetch(k + 1, fj1, fi1);
-                apply(fj0, fi0);
-                if (k + 1 < p) {
-                    if (k + 2 < p) fetch(k + 2, fj0, fi0);
-                    apply(fj1, fi1);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < MID_MAXI; ++u) {
-                const int i = p + wave + SM_WAVES * u;
-                if (i <= NB) {
-                    double* B = Cp + ((i - p) << 8);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) B[(lg + 4 * v) * SB + li] = acc[u][v];
-                }
-            }
+        if (!FL) {
+            for (int idx = tid; idx < nd.nF * SB; idx += SM_THREADS) fl[idx] = featg[(idx >> 4) * NP + SB * p + (idx & 15)];
+            __syncthreads();
         }
+        // ---- accumulate: block rows i = p + wave + 8u <= NB
+        mc.p = p;
+        const int nrows = (NB - p - wave >= 0) ? (NB - p - wave) / SM_WAVES + 1 : 0;     // scalar
+        switch (nrows) {
+            case 1: mid_accumulate<1, FL>(nd, mc); break;
+            case 2: mid_accumulate<2, FL>(nd, mc); break;
+            case 3: mid_accumulate<3, FL>(nd, mc); break;
+            case 4: mid_accumulate<4, FL>(nd, mc); break;
+            case 5: mid_accumulate<5, FL>(nd, mc); break;
+            case 6: mid_accumulate<6, FL>(nd, mc); break;
+            default: break;
+        }
+        MID_STAMP(tt, 2);
         __syncthreads();
-        // ---- factor + panel on the LDS image of the column: rows below the diagonal block = 16 (NBa - p - 1)
+        MID_STAMP(tt, 3);
+        // ---- factor + panel on the LDS image of the column: rows below the diagonal block = 16 (NBa - p - 1); the
+        //      finished rows go straight from the registers to the scratch, for the columns to come
         {
             const int rows = SB * (NBa - p - 1);
             for (int q0 = 0; q0 < rows; q0 += 48 * SM_WAVES) {
-                if (q0 + wave * 48 < rows) {                                 // wave-uniform: this wave carries rows
+                if (q0 + wave * 48 < rows) {                                 // scalar: this wave carries rows
                     const bool is_diag = lane < SB;
                     const int q = q0 + wave * 48 + (lane - SB);
                     double r[SB];
-                    double* dst = nullptr;
-                    if (is_diag) dst = Cp + li;
-                    else if (q < rows) dst = Cp + (((q >> 4) + 1) << 8) + (q & 15);
-                    if (dst) {
+                    const double* src = nullptr;
+                    if (is_diag) src = Cp + li;
+                    else if (q < rows) src = Cp + (((q >> 4) + 1) << 8) + (q & 15);
+                    if (src) {
 #pragma unroll
-                        for (int c = 0; c < SB; ++c) r[c] = dst[c * SB];
+                        for (int c = 0; c < SB; ++c) r[c] = src[c * SB];
                     } else {
 #pragma unroll
                         for (int c = 0; c < SB; ++c) r[c] = 0.0;
@@ -374,22 +451,23 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
                     sm_factor_rows(r, li, SB * p, bad, lcc);
                     if (is_diag) {
                         if (wave == 0 && q0 == 0) ldv[SB * p + li] = lcc;
-                    } else if (dst) {
+                    } else if (src) {
+                        double* dst = MBLK(p + 1 + (q >> 4), p) + (q & 15);
 #pragma unroll
                         for (int c = 0; c < SB; ++c) dst[c * SB] = r[c];
                     }
                 }
             }
         }
-        __syncthreads();
-        // ---- store the column's X blocks (i > p) for the columns to come
-        for (int idx = tid; idx < (NBa - p - 1) * 256; idx += SM_THREADS) {
-            const int i = p + 1 + (idx >> 8);
-            MBLK(i, p)[idx & 255] = Cp[256 + idx];
-        }
+        MID_STAMP(tt, 4);
         __threadfence_block();
         __syncthreads();
+        MID_STAMP(tt, 5);
     }
+#ifdef GPSLC_DIAG
+    if (a.stamps && blockIdx.x == 0 && lane == 0)
+        for (int j = 0; j < 6; ++j) a.stamps[8 * (long long)gridDim.x + 8 * wave + j] = (double)tt[j];
+#endif
 
     if (wave == 0) {      // z = row 0 of the right-hand side blocks (NB, k): z[16k + c] = X(NB, k)[c*16 + 0]
         double q = 0.0, ld = 0.0;
@@ -417,17 +495,32 @@ size_t mid_gp_scratch_doubles(int n, int nF) {
     const long long NB = (n + SB - 1) / SB, NBa = NB + 1;
     return (size_t)(NBa * (NBa + 1) / 2 * 256 + (long long)(nF + 1) * NB * SB);
 }
+// LDS with the features resident (preferred) / staged per block column
+static size_t mid_lds_resident(int n, int nF) {
+    const size_t NB = (n + SB - 1) / SB;
+    return ((NB + 1) * 256 + NB * SB + (size_t)(nF + 1) * NB * SB) * 8;
+}
+static size_t mid_lds_staged(int n, int nF) {
+    const size_t NB = (n + SB - 1) / SB;
+    return ((NB + 1) * 256 + NB * SB + (size_t)nF * SB) * 8;
+}
 size_t mid_gp_lds_bytes(int n, int nF) {
-    const int NB = (n + SB - 1) / SB;
-    return ((size_t)(NB + 1) * 256 + (size_t)NB * SB + (size_t)nF * SB) * 8;
+    const size_t r = mid_lds_resident(n, nF);
+    return r <= 160 * 1024 ? r : mid_lds_staged(n, nF);
 }
 bool mid_gp_fits(int n) { return (n + SB - 1) / SB + 1 <= SM_WAVES * MID_MAXI && n <= 640; }
 
-void launch_mid_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st) {
-    const size_t bytes = mid_gp_lds_bytes(a.n, nF_max);
+template <bool FL>
+static void launch_mid_inst(const SmallArgs& a, int count, size_t bytes, hipStream_t st) {
     static DeviceOnce once;
-    lds_opt_in(once, (const void*)mid_gp_logpdf_kernel, 160 * 1024);
-    hipLaunchKernelGGL(mid_gp_logpdf_kernel, dim3(count), dim3(SM_THREADS), bytes, st, a);
+    lds_opt_in(once, (const void*)mid_gp_logpdf_kernel<FL>, 160 * 1024);
+    hipLaunchKernelGGL((mid_gp_logpdf_kernel<FL>), dim3(count), dim3(SM_THREADS), bytes, st, a);
+}
+
+void launch_mid_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st) {
+    const bool resident = mid_lds_resident(a.n, nF_max) <= 160 * 1024;
+    if (resident) launch_mid_inst<true>(a, count, mid_lds_resident(a.n, nF_max), st);
+    else launch_mid_inst<false>(a, count, mid_lds_staged(a.n, nF_max), st);
 }
 
 size_t small_gp_lds_bytes(int n, int nF) {
