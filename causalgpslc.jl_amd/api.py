@@ -505,11 +505,14 @@ def gpLogpdf(F, LS, scale, noise, target, ctx: Optional[Context] = None):
     return out
 
 
-def nodesLogpdf(nodes, ctx: Context):
+def nodesLogpdf(nodes, ctx: Context, fail_value=None):
     """The fused whole-model score (gpslc_nodes_logpdf): ``nodes`` is a sequence of (F, LS, scale, noise, target)
     — F (n, nF) or None, LS (nF,), scalars, target (n,) — one per Gen address to re-score (:X => k => :X, :T /
-    :logitT, :Y with F = [U | X | T]; src/model_likelihood.jl:13-120).  One call, and for n <= ~160 one kernel
-    launch, whatever the nodes' feature counts.  Returns the log-densities (len(nodes),)."""
+    :logitT, :Y with F = [U | X | T]; src/model_likelihood.jl:13-120).  One call, and for n <= 640 one kernel
+    launch, whatever the nodes' feature counts.  Returns the log-densities (len(nodes),).
+    A covariance that is not positive definite raises PosDefException (PDMats' behaviour inside Gen's mvnormal);
+    with ``fail_value`` given, the failing nodes (gpslc_last_info) get that value instead and the others keep
+    their scores — what a batch of independent MH proposals needs."""
     cnt = len(nodes)
     arr = (_lib.Node * max(cnt, 1))()
     keep = []
@@ -532,6 +535,9 @@ def nodesLogpdf(nodes, ctx: Context):
         arr[i].target = tg.ctypes.data
     out = np.empty(cnt)
     st = ctx.lib.gpslc_nodes_logpdf(ctx.h, cnt, C.cast(arr, C.c_void_p), _p(out))
+    if st > 0 and fail_value is not None:
+        out[ctx.last_info(cnt) != 0] = fail_value
+        return out
     ctx.check(st)
     return out
 

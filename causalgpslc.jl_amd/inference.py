@@ -307,12 +307,19 @@ class _RealTChain:
     TOUCH = {"uNoise": "u", "tNoise": "t", "yNoise": "y", "tyLS": "y", "tScale": "t", "yScale": "y",
              "utLS": "t", "uyLS": "y", "uxLS": "x", "xNoise": "x", "xScale": "x", "xtLS": "t", "xyLS": "y"}
 
-    def mh(self, name, i=None, j=None):
-        """One `mh(trace, paramProposal, (drift, addr))` (src/inference.jl:22-45, :78-89): `i`, `j` as in
-        getProposalAddress (src/proposal.jl:7-24), 0-based here."""
+    def _draw(self, name, i=None, j=None):
+        """The random numbers of one MH move: the InvGamma drift proposal (src/proposal.jl:32-41) and the acceptance
+        uniform, in that order.  Both depend only on the address's current value, so a sweep can draw them for all
+        its addresses up front, in the reference's address order, whatever the schedule of the scores."""
         cur = self.v[name] if i is None else (self.v[name][i] if j is None else self.v[name][i][j])
         sh, sc = _proposal_params(cur, self.pp["drift"])
-        new = sc / self.rng.gamma(sh)
+        return sc / self.rng.gamma(sh), math.log(self.rng.random())
+
+    def _propose(self, name, i=None, j=None, draw=None):
+        """The proposal half of one `mh(trace, paramProposal, (drift, addr))`."""
+        cur = self.v[name] if i is None else (self.v[name][i] if j is None else self.v[name][i][j])
+        sh, sc = _proposal_params(cur, self.pp["drift"])
+        new, log_unif = draw if draw is not None else self._draw(name, i, j)
         shb, scb = _proposal_params(new, self.pp["drift"])
         v2 = dict(self.v)
         if i is not None:
@@ -326,37 +333,95 @@ class _RealTChain:
             v2[name] = new
         node = self.TOUCH[name]
         xk = (j if name == "uxLS" else i) if node == "x" else None
-        old_s = {"u": self.s_u, "t": self.s_t, "y": self.s_y}.get(node)
-        if node == "x":
-            old_s = self.s_x[xk]
-        try:
-            if node == "u":
-                new_s = self.score_u(uNoise=new)
-            elif node == "t":
-                new_s = self.score_t(v2)
-            elif node == "y":
-                new_s = self.score_y(v2)
-            else:
-                new_s = self.score_x(v2, only=xk)
-        except api.PosDefException:
-            return False
-        log_a = (new_s - old_s
-                 + _invgamma_logpdf(new, self.pp[name + "Shape"], self.pp[name + "Scale"])
+        log_q = (_invgamma_logpdf(new, self.pp[name + "Shape"], self.pp[name + "Scale"])
                  - _invgamma_logpdf(cur, self.pp[name + "Shape"], self.pp[name + "Scale"])
                  + _invgamma_logpdf(cur, shb, scb) - _invgamma_logpdf(new, sh, sc))
-        if math.log(self.rng.random()) < log_a:
-            self.v = v2
-            if node == "u":
-                self.s_u = new_s
-            elif node == "t":
-                self.s_t = new_s
-            elif node == "y":
-                self.s_y = new_s
+        return {"name": name, "i": i, "j": j, "new": new, "v2": v2, "node": node, "xk": xk, "log_q": log_q,
+                "log_unif": log_unif}
+
+    def _old_score(self, pr):
+        return self.s_x[pr["xk"]] if pr["node"] == "x" else {"u": self.s_u, "t": self.s_t, "y": self.s_y}[pr["node"]]
+
+    def _decide(self, pr, new_s):
+        """The accept / reject half: `new_s` = the touched node's score under the proposal (-inf: not positive
+        definite, which Gen would have thrown on; here the move is rejected)."""
+        if not pr["log_unif"] < new_s - self._old_score(pr) + pr["log_q"]:
+            return False
+        name, i, j, new = pr["name"], pr["i"], pr["j"], pr["new"]
+        if i is None:
+            self.v[name] = new
+        else:                             # element-wise: other entries of the array may have moved in the same batch
+            arr = self.v[name].copy()
+            if j is None:
+                arr[i] = new
             else:
-                self.s_x = self.s_x.copy()
-                self.s_x[xk] = new_s
-            return True
-        return False
+                arr[i][j] = new
+            self.v[name] = arr
+        if pr["node"] == "u":
+            self.s_u = new_s
+        elif pr["node"] == "t":
+            self.s_t = new_s
+        elif pr["node"] == "y":
+            self.s_y = new_s
+        else:
+            self.s_x = self.s_x.copy()
+            self.s_x[pr["xk"]] = new_s
+        return True
+
+    def mh(self, name, i=None, j=None, draw=None):
+        """One `mh(trace, paramProposal, (drift, addr))` (src/inference.jl:22-45, :78-89): `i`, `j` as in
+        getProposalAddress (src/proposal.jl:7-24), 0-based here.  One score call for the one node it touches."""
+        pr = self._propose(name, i, j, draw)
+        try:
+            if pr["node"] == "u":
+                new_s = self.score_u(uNoise=pr["new"])
+            elif pr["node"] == "t":
+                new_s = self.score_t(pr["v2"])
+            elif pr["node"] == "y":
+                new_s = self.score_y(pr["v2"])
+            else:
+                new_s = self.score_x(pr["v2"], only=pr["xk"])
+        except api.PosDefException:
+            new_s = -math.inf
+        return self._decide(pr, new_s)
+
+    def _gp_node(self, pr):
+        """(F, LS, scale, noise, target) of the node a proposal touches, under the proposal's parameters."""
+        v2 = pr["v2"]
+        if pr["node"] == "x":
+            k = pr["xk"]
+            return (self._umodel(), self._uxls_model(v2)[k], v2["xScale"][k], v2["xNoise"][k], self.X[:, k])
+        if pr["node"] == "t":
+            F, ls = self._t_features(None, v2)
+            return (F, ls, v2["tScale"], v2["tNoise"], self.logitT if self.binary else self.T)
+        cols = ([self._umodel()] if self.nU else []) + ([self.X] if self.nX else []) + [self.T]
+        ls = np.concatenate(([v2["uyLS"]] if self.nU else []) + ([v2["xyLS"]] if self.nX else []) + [[v2["tyLS"]]])
+        return (np.column_stack(cols), ls, v2["yScale"], v2["yNoise"], self.Y)
+
+    def mh_batch(self, addrs, draws=None):
+        """MH moves on addresses that touch DIFFERENT nodes, scored in one fused call (gpslc_nodes_logpdf: one
+        workgroup per node, one launch).  Given U (and logitT) the model's density factorises over its nodes and no
+        two nodes share a hyper-parameter, so these moves neither see nor affect one another: taking them together
+        is the same Markov kernel as taking them one after the other."""
+        props = [self._propose(*(tuple(a) + (None,) * (3 - len(a))), None if draws is None else draws[a]) for a in addrs]
+        assert len({(p_["node"], p_["xk"]) for p_ in props}) == len(props), "addresses of one batch must touch distinct nodes"
+        gp = [p_ for p_ in props if p_["node"] != "u"]
+        scores = {}
+        if gp:
+            out = api.nodesLogpdf([self._gp_node(p_) for p_ in gp], self.ctx, fail_value=-math.inf)
+            for p_, sc in zip(gp, out):
+                scores[id(p_)] = float(sc)
+        acc = 0
+        for p_ in props:
+            if p_["node"] == "u":
+                try:
+                    new_s = self.score_u(uNoise=p_["new"])
+                except api.PosDefException:
+                    new_s = -math.inf
+            else:
+                new_s = scores[id(p_)]
+            acc += self._decide(p_, new_s)
+        return acc
 
     def elliptical_slice(self, k):
         """`elliptical_slice(trace, :U => k => :U, zeros(n), uCov)` (src/inference.jl:48-54, :92-98)."""
@@ -384,25 +449,45 @@ class _RealTChain:
             theta = self.rng.uniform(lo, hi)
         # bracket collapsed onto the current state: keep it
 
-    def sweep_mh(self):
-        """One inner sweep in the reference's address order (src/inference.jl:23-44 / :78-89 with U,
+    def sweep_addresses(self):
+        """The addresses of one inner sweep in the reference's order (src/inference.jl:23-44 / :78-89 with U,
         :126-139 / :324-337 NoU with covariates, :158-160 / :372-374 NoU NoCov)."""
         if not self.nU and not self.nX:
-            self.mh("yNoise"); self.mh("tyLS"); self.mh("yScale")                       # noqa: E702
-            return
-        if self.nU:
-            self.mh("uNoise")
-        self.mh("tNoise"); self.mh("yNoise"); self.mh("tyLS")                           # noqa: E702
+            return [("yNoise",), ("tyLS",), ("yScale",)]
+        out = [("uNoise",)] if self.nU else []
+        out += [("tNoise",), ("yNoise",), ("tyLS",)]
         for k in range(self.nU):
-            self.mh("utLS", k); self.mh("uyLS", k)                                      # noqa: E702
-            for l in range(self.nX):
-                self.mh("uxLS", k, l)
+            out += [("utLS", k), ("uyLS", k)]
+            out += [("uxLS", k, l) for l in range(self.nX)]
         for k in range(self.nX):
             if self.nU:
-                self.mh("xNoise", k); self.mh("xtLS", k); self.mh("xyLS", k); self.mh("xScale", k)   # noqa: E702
+                out += [("xNoise", k), ("xtLS", k), ("xyLS", k), ("xScale", k)]
             else:
-                self.mh("xtLS", k); self.mh("xyLS", k)                                  # noqa: E702
-        self.mh("tScale"); self.mh("yScale")                                            # noqa: E702
+                out += [("xtLS", k), ("xyLS", k)]
+        return out + [("tScale",), ("yScale",)]
+
+    def sweep_mh(self, batched=True):
+        """One inner sweep.  ``batched=False``: address by address, one score call each — the reference's schedule.
+        ``batched=True`` (default): the sweep is split into its per-node address chains (the :Y chain yNoise, tyLS,
+        uyLS.., xyLS.., yScale; the :T chain; one chain per :X => k => :X; uNoise for the U prior), each kept in
+        the reference's order, and step t of every chain is scored in ONE fused call (`mh_batch`): 2 + nU + nX + 1
+        calls per sweep instead of one per address (IHDP, nU = 1, nX = 6: 10 instead of 38).  Moves on different
+        nodes commute (see `mh_batch`), so this is the same transition kernel — and since an address's random
+        numbers depend only on its own current value, they are drawn up front in the reference's address order:
+        both schedules produce the SAME chain, bit for bit (tests/test_gpu_neec.py)."""
+        addrs = self.sweep_addresses()
+        draws = {a: self._draw(*a) for a in addrs}
+        if not batched:
+            for a in addrs:
+                self.mh(*(tuple(a) + (None,) * (3 - len(a))), draw=draws[a])
+            return
+        chains = {}
+        for a in addrs:
+            node = self.TOUCH[a[0]]
+            key = (node, (a[2] if a[0] == "uxLS" else a[1]) if node == "x" else None)
+            chains.setdefault(key, []).append(a)
+        for t in range(max(len(c) for c in chains.values())):
+            self.mh_batch([c[t] for c in chains.values() if t < len(c)], draws)
 
     def snapshot(self):
         out = {k: (val.copy() if isinstance(val, np.ndarray) else val) for k, val in self.v.items()}

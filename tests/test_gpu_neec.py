@@ -195,3 +195,40 @@ def test_documented_example_workflow_runs(gp):
     # the per-level SATE curve of the draws follows the deterministic MeanITE
     ms, _, _ = gp.predict(g, doT)
     assert np.max(np.abs(ite.mean(axis=(1, 2)) - ms.mean(axis=0))) < 0.05
+
+
+@pytest.mark.parametrize("data,nU,binary", [("IHDP_sampled.csv", 1, True), ("NEEC_sampled.csv", 2, False)])
+def test_batched_sweep_is_the_sequential_sweep(gp, data, nU, binary):
+    """`sweep_mh(batched=True)` scores step t of every per-node address chain in one fused call; moves on different
+    nodes commute and an address's random numbers are drawn up front in the reference's address order, so the chain
+    is the one the address-by-address schedule (src/inference.jl:23-44) produces — bit for bit."""
+    from causalgpslc_jl_amd import inference as inf
+    SigmaU, obj, X, T, Y = gp.prepareData(os.path.join(GOLD, data), 1e-6)
+    pp = gp.getPriorParameters()
+    pp["SigmaU"] = SigmaU
+    snaps = []
+    for batched in (False, True):
+        ch = inf._RealTChain(pp, SigmaU, X, T, Y, nU, np.random.Generator(np.random.Philox(5)), binary=binary)
+        for _ in range(3):
+            ch.sweep_mh(batched=batched)
+            if binary:
+                ch.elliptical_slice_logitT()
+            ch.elliptical_slice(0)
+        snaps.append((ch.snapshot(), ch.s_x.copy(), ch.s_t, ch.s_y, ch.s_u))
+    a, b = snaps
+    for k in a[0]:
+        va, vb = a[0][k], b[0][k]
+        if isinstance(va, list):
+            assert all(np.array_equal(x, y) for x, y in zip(va, vb)), k
+        else:
+            assert np.array_equal(va, vb), k
+    assert np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    # the schedule: one fused call per step of the longest chain
+    ch = inf._RealTChain(pp, SigmaU, X, T, Y, nU, np.random.Generator(np.random.Philox(5)), binary=binary)
+    nX = 0 if X is None else X.shape[1]
+    chains = {}
+    for adr in ch.sweep_addresses():
+        node = ch.TOUCH[adr[0]]
+        chains.setdefault((node, (adr[2] if adr[0] == "uxLS" else adr[1]) if node == "x" else None), []).append(adr)
+    assert max(len(c) for c in chains.values()) == 2 + nU + nX + 1        # the :Y chain: yNoise, tyLS, uyLS.., xyLS.., yScale
+    assert sum(len(c) for c in chains.values()) == len(ch.sweep_addresses())
