@@ -224,16 +224,19 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
 // The same score for the sizes between the LDS-resident kernel and the batched tiled path (176 < n <= 640: IHDP
 // n = 272): one workgroup per node, LEFT-looking over block columns.  Only the current block column lives in LDS; the
 // finished columns X(i, k) = L blocks sit in a per-node global scratch that stays in L2 (n = 272: 306 KiB).
-// Per block column p:
-//   accumulate  every wave owns up to MID_MAXI block rows i >= p: the Gram block (i, p) is evaluated straight into the
-//               MFMA accumulator layout and  -= sum_{k<p} X(i,k) X(p,k)^T  runs with the accumulators in registers for the
-//               whole k loop (operand fragments are 512-byte coalesced reads of the scratch; X(p,k) is shared by the
-//               wave's rows) — no read-modify-write of a trailing matrix anywhere;
-//   factor+panel  exactly the register-resident column operations of the small kernel (sm_factor_rows) on the LDS
-//               image of the column, 48 rows per wave and pass;
-//   store       the column's X blocks go to the scratch for the columns to come.
+// Every wave owns up to MID_MAXI block rows of a column and keeps their 16 x 16 blocks in MFMA accumulators from the
+// Gram evaluation to the hand-over to the factorisation.  Step p of the main loop, two barriers:
+//   phase B   waves that carry rows: factor + panel of column p — exactly the register-resident column operations of the
+//             small kernel (sm_factor_rows) on the LDS image of the column, 48 rows per wave; the finished rows go
+//             from the registers straight to the scratch.
+//             EVERY wave, for its rows of column p + 1: Gram blocks straight into the accumulator layout, then
+//             -= sum_{k<p} X(i,k) X(p+1,k)^T  (operand fragments: 512-byte coalesced reads of the scratch through a
+//             ring of register sets; X(p+1,k) is shared by the wave's rows).  None of this needs column p, so it runs
+//             while column p is being factored; block rows are dealt from the LAST wave downwards, so that the waves
+//             that carry the factorisation (the first ones) own the fewest rows.
+//   phase A   the one k step that needs column p, then the accumulators become the LDS image of column p + 1.
 // The right-hand side rides along as block row NB (its row 0 = target, the other 15 rows zero): z = L^-1 target
-// falls out of the same block operations, no special case.  Three barriers per block column.
+// falls out of the same block operations, no special case.
 // ---------------------------------------------------------------------------------------------------------------------
 #define MID_MAXI 6         // block rows per wave at most: (NB + 1) <= 8 * MID_MAXI  ->  NB <= 47, limited to n <= 640 by the host
 #define MBLK(i, j) (X + ((((long long)(i) * ((i) + 1)) / 2 + (j)) << 8))     // scratch: packed lower blocks, rows 0..NB
@@ -244,12 +247,16 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
 __host__ __device__ constexpr int mid_nset(int R) { return R <= 1 ? 6 : R == 2 ? 5 : R == 3 ? 4 : R == 4 ? 3 : 2; }
 
 struct MidCtx {
-    const double* X;        // scratch: finished block columns
-    double* Cp;             // LDS image of the current block column
+    double* X;              // scratch: finished block columns
+    double* Cp;             // LDS image of the block column being factored: slot (i - p) = block (i, p)
+    double* Cn;             // LDS image of the next block column under construction (== Cp without the second buffer)
+    double* ldv;            // LDS: diag(L)
+    double* Xrow;           // LDS (XR): the finished blocks X(q, 0 .. q-2) of the block row the next k loop shares
     const double* fl;       // LDS features (FL: [f][NP]; else the block column's [f][16])
     const double* featg;    // !FL: features in the scratch [f][NP]
     const double* tgt;      // right-hand side [NP]
-    int n, NB, NP, p, wave, lane;
+    int n, NB, NP, wave, lane, tid;
+    int own;                // block rows of column q owned by this wave: i = q + own + 8u (own = 7 - wave)
 #ifdef GPSLC_DIAG
     long long* tt;          // per-wave phase clocks (measurement build)
 #endif
@@ -260,79 +267,81 @@ struct MidCtx {
 #define MID_STAMP(tt, j) do { } while (0)
 #endif
 
-// accumulate phase of block column p for a wave that owns EXACTLY R block rows i = p + wave + 8u, u < R (the last one
-// may be the right-hand side row NB).  R is a template parameter and `wave` a scalar, so the body is straight-line
-// code: the compiler counts the outstanding loads exactly (s_waitcnt vmcnt(N)) and the prefetch ring really overlaps.
+// Gram blocks (i, q) of the wave's R rows together: element (row 16i + li, col 16q + lg + 4v); the feature loop is the outer
+// one: 4 R independent distance / exp chains in flight.  A right-hand side row (i == NB) computes a throw-away block
+// on the last real block row's features and is then overwritten with the target.
 template <int R, bool FL>
-__device__ __forceinline__ void mid_accumulate(const SmallNode& nd, const MidCtx& c) {
-    constexpr int NSET = mid_nset(R);
-    const double* X = c.X;
-    const int p = c.p, lane = c.lane, li = lane & 15, lg = lane >> 4, NP = c.NP, NB = c.NB, n = c.n;
-    const int i0 = p + c.wave;
+__device__ __forceinline__ void mid_gram(const SmallNode& nd, const MidCtx& c, int q, d4 (&acc)[R]) {
+    const int lane = c.lane, li = lane & 15, lg = lane >> 4, NP = c.NP, NB = c.NB, n = c.n;
+    const int i0 = q + c.own;
     const bool last_rhs = (i0 + SM_WAVES * (R - 1) == NB);       // scalar
-    d4 acc[R];
-    // Gram blocks (i, p) of all the wave's rows together: element (row 16i + li, col 16p + lg + 4v); the feature loop is
-    // the outer one: 4 R independent distance / exp chains in flight.  The right-hand side row computes a throw-away
-    // block on the last real block row's features.
-    {
-        double lux[R][4];
+    double lux[R][4];
 #pragma unroll
-        for (int u = 0; u < R; ++u)
+    for (int u = 0; u < R; ++u)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) lux[u][v] = 0.0;
-        if (!nd.cov) {
-            for (int f = 0; f < nd.nF; ++f) {
-                double cf[4];
+        for (int v = 0; v < 4; ++v) lux[u][v] = 0.0;
+    if (!nd.cov) {
+        for (int f = 0; f < nd.nF; ++f) {
+            double cf[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) cf[v] = FL ? c.fl[f * NP + SB * p + lg + 4 * v] : c.fl[f * SB + lg + 4 * v];
-#pragma unroll
-                for (int u = 0; u < R; ++u) {
-                    const int i = min(i0 + SM_WAVES * u, NB - 1);
-                    const double xr = FL ? c.fl[f * NP + SB * i + li] : c.featg[f * NP + SB * i + li];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const double d = xr - cf[v];
-                        lux[u][v] = fma(d, d, lux[u][v]);
-                    }
-                }
-            }
-        }
-        if (nd.cov) {        // dense covariance handed over by the caller (scalar branch: one code path per node)
+            for (int v = 0; v < 4; ++v) cf[v] = FL ? c.fl[f * NP + SB * q + lg + 4 * v] : c.fl[f * SB + lg + 4 * v];
 #pragma unroll
             for (int u = 0; u < R; ++u) {
-                const int gi = SB * min(i0 + SM_WAVES * u, NB - 1) + li;
+                const int i = min(i0 + SM_WAVES * u, NB - 1);
+                const double xr = FL ? c.fl[f * NP + SB * i + li] : c.featg[f * NP + SB * i + li];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const int gj = SB * p + lg + 4 * v;
-                    const bool in = gi < n && gj < n;
-                    const double cv = nd.cov[in ? (long long)gj * n + gi : 0];
-                    acc[u][v] = in ? nd.covscale * cv : (gi == gj ? 1.0 : 0.0);
+                    const double d = xr - cf[v];
+                    lux[u][v] = fma(d, d, lux[u][v]);
                 }
             }
-        } else {             // branch-free: the exp chains of all 4 R entries interleave
-#pragma unroll
-            for (int u = 0; u < R; ++u) {
-                const int gi = SB * min(i0 + SM_WAVES * u, NB - 1) + li;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int gj = SB * p + lg + 4 * v;
-                    const double e = nd.scale * gp_exp_neg(-lux[u][v]) + (gi == gj ? nd.noise : 0.0);
-                    acc[u][v] = (gi < n && gj < n) ? e : (gi == gj ? 1.0 : 0.0);
-                }
-            }
-        }
-        if (last_rhs) {      // right-hand side block: row 0 = target
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[R - 1][v] = (li == 0) ? c.tgt[SB * p + lg + 4 * v] : 0.0;
         }
     }
-    MID_STAMP(c.tt, 0);
-    // k loop: a ring of NSET operand sets, unrolled by NSET so that the set indices are static
+    if (nd.cov) {        // dense covariance handed over by the caller (scalar branch: one code path per node)
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int gi = SB * min(i0 + SM_WAVES * u, NB - 1) + li;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int gj = SB * q + lg + 4 * v;
+                const bool in = gi < n && gj < n;
+                const double cv = nd.cov[in ? (long long)gj * n + gi : 0];
+                acc[u][v] = in ? nd.covscale * cv : (gi == gj ? 1.0 : 0.0);
+            }
+        }
+    } else {             // branch-free: the exp chains of all 4 R entries interleave
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int gi = SB * min(i0 + SM_WAVES * u, NB - 1) + li;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int gj = SB * q + lg + 4 * v;
+                const double e = nd.scale * gp_exp_neg(-lux[u][v]) + (gi == gj ? nd.noise : 0.0);
+                acc[u][v] = (gi < n && gj < n) ? e : (gi == gj ? 1.0 : 0.0);
+            }
+        }
+    }
+    if (last_rhs) {      // right-hand side block: row 0 = target
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[R - 1][v] = (li == 0) ? c.tgt[SB * q + lg + 4 * v] : 0.0;
+    }
+}
+
+// acc(i, q) -= sum_{k0 <= k < k1} X(i,k) X(q,k)^T for the wave's R rows: a ring of NSET operand sets, unrolled by NSET so
+// that the set indices are static.  R is a template parameter and the wave index a scalar, so the body is straight-line
+// code: the compiler counts the outstanding loads exactly (s_waitcnt vmcnt(N)) and the prefetch ring really overlaps.
+// XR: the shared operand X(q, k) comes from its LDS copy (staged once per column for all eight waves) instead of the scratch
+template <int R, bool XR>
+__device__ __forceinline__ void mid_kloop(const MidCtx& c, int q, int k0, int k1, d4 (&acc)[R]) {
+    constexpr int NSET = mid_nset(R);
+    const double* X = c.X;
+    const int lane = c.lane;
+    const int i0 = q + c.own;
     double fj[NSET][4], fi[NSET][R][4];
     auto fetch = [&](int k, double (&fjs)[4], double (&fis)[R][4]) {
-        const double* Xpk = MBLK(p, k);
+        const double* Xqk = XR ? c.Xrow + (k << 8) : MBLK(q, k);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fjs[kk] = sm_frag(Xpk, kk, lane);
+        for (int kk = 0; kk < 4; ++kk) fjs[kk] = sm_frag(Xqk, kk, lane);
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             const double* Xik = MBLK(i0 + SM_WAVES * u, k);
@@ -348,41 +357,133 @@ __device__ __forceinline__ void mid_accumulate(const SmallNode& nd, const MidCtx
     };
 #pragma unroll
     for (int s = 0; s < NSET - 1; ++s)
-        if (s < p) fetch(s, fj[s], fi[s]);
-    for (int k0 = 0; k0 < p; k0 += NSET) {
+        if (k0 + s < k1) fetch(k0 + s, fj[s], fi[s]);
+    for (int kb = k0; kb < k1; kb += NSET) {
 #pragma unroll
         for (int s = 0; s < NSET; ++s) {
-            const int k = k0 + s;
-            if (k < p) {
-                if (k + NSET - 1 < p) fetch(k + NSET - 1, fj[(s + NSET - 1) % NSET], fi[(s + NSET - 1) % NSET]);
+            const int k = kb + s;
+            if (k < k1) {
+                if (k + NSET - 1 < k1) fetch(k + NSET - 1, fj[(s + NSET - 1) % NSET], fi[(s + NSET - 1) % NSET]);
                 apply(fj[s], fi[s]);
             }
         }
     }
-    MID_STAMP(c.tt, 1);
+}
+
+// factor + panel of column p on its LDS image: rows below the diagonal block = 16 (NBa - p - 1), 48 per wave and pass.
+// DB: the finished rows also replace their LDS image, which phase A reads its operands from.
+template <bool DB>
+__device__ __forceinline__ void mid_factor(const MidCtx& c, int p, int& bad) {
+    double* X = c.X;
+    const int lane = c.lane, li = lane & 15, wave = c.wave;
+    const int rows = SB * (c.NB + 1 - p - 1);
+    for (int q0 = 0; q0 < rows; q0 += 48 * SM_WAVES) {
+        if (q0 + wave * 48 < rows) {                                 // scalar: this wave carries rows
+            const bool is_diag = lane < SB;
+            const int q = q0 + wave * 48 + (lane - SB);
+            double r[SB];
+            double* src = nullptr;
+            if (is_diag) src = c.Cp + li;
+            else if (q < rows) src = c.Cp + (((q >> 4) + 1) << 8) + (q & 15);
+            if (src) {
 #pragma unroll
-    for (int u = 0; u < R; ++u) {
-        double* B = c.Cp + ((c.wave + SM_WAVES * u) << 8);
+                for (int cc = 0; cc < SB; ++cc) r[cc] = src[cc * SB];
+            } else {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) B[(lg + 4 * v) * SB + li] = acc[u][v];
+                for (int cc = 0; cc < SB; ++cc) r[cc] = 0.0;
+            }
+            double lcc;
+            sm_factor_rows(r, li, SB * p, bad, lcc);
+            if (is_diag) {
+                if (wave == 0 && q0 == 0) c.ldv[SB * p + li] = lcc;
+            } else if (src) {
+                double* dst = MBLK(p + 1 + (q >> 4), p) + (q & 15);
+#pragma unroll
+                for (int cc = 0; cc < SB; ++cc) dst[cc * SB] = r[cc];
+                if (DB) {
+#pragma unroll
+                    for (int cc = 0; cc < SB; ++cc) src[cc * SB] = r[cc];
+                }
+            }
+        }
     }
+}
+
+// the k step that needs column p, operands from the LDS image of column p: X(q, p) = slot 1, X(i, p) = slot i - p
+template <int R>
+__device__ __forceinline__ void mid_kstep_lds(const MidCtx& c, d4 (&acc)[R]) {
+    const int lane = c.lane;
+    double fj[4], fi[R][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fj[kk] = sm_frag(c.Cp + 256, kk, lane);
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fi[u][kk] = sm_frag(c.Cp + ((c.own + SM_WAVES * u + 1) << 8), kk, lane);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int u = 0; u < R; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(fj[kk], fi[u][kk], acc[u], 0, 0, 1);
+}
+
+// one step of the main loop for a wave that owns EXACTLY R block rows of column q = p + 1 (p = -1: the first column)
+template <int R, bool FL, bool DB, bool XR>
+__device__ __forceinline__ void mid_step(const SmallNode& nd, const MidCtx& c, int p, int& bad) {
+    const int q = p + 1;
+    constexpr int RA = R > 0 ? R : 1;
+    d4 acc[RA];
+    if (p >= 0) mid_factor<DB>(c, p, bad);
+    MID_STAMP(c.tt, 4);
+    if (R > 0) {
+        mid_gram<RA, FL>(nd, c, q, acc);
+        MID_STAMP(c.tt, 0);
+        if (p > 0) mid_kloop<RA, XR>(c, q, 0, p, acc);
+        MID_STAMP(c.tt, 1);
+    }
+    __threadfence_block();
+    __syncthreads();                 // column p is finished: in the scratch (and, DB, in its LDS image)
+    MID_STAMP(c.tt, 3);
+    if (XR && p >= 0 && q + 1 < c.NB) {      // the next column's shared operand row: blocks (q + 1, 0 .. p), contiguous in the scratch
+        const double* X = c.X;
+        const double* src = MBLK(q + 1, 0);
+        for (int idx = c.tid; idx < (p + 1) * 256; idx += SM_THREADS) c.Xrow[idx] = src[idx];
+    }
+    if (R > 0) {
+        if (p >= 0) {
+            if (DB) mid_kstep_lds<RA>(c, acc);
+            else mid_kloop<RA, false>(c, q, p, p + 1, acc);
+        }
+        const int li = c.lane & 15, lg = c.lane >> 4;
+#pragma unroll
+        for (int u = 0; u < RA; ++u) {
+            double* B = c.Cn + ((c.own + SM_WAVES * u) << 8);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) B[(lg + 4 * v) * SB + li] = acc[u][v];
+        }
+    }
+    MID_STAMP(c.tt, 2);
+    __syncthreads();                 // the LDS image of column q is complete
+    MID_STAMP(c.tt, 5);
 }
 
 // FL    scaled features + target resident in LDS for the whole kernel (they fit for every size the reference uses);
 //       otherwise they sit in the scratch and the 16 instances of the current block column are staged per column
-template <bool FL>
+// DB    two LDS column images: the factored column p stays readable (operands of the one k step that needs it) while
+//       column p + 1 is written
+// XR    an LDS copy of the block row X(q, .) every wave's k loop shares
+template <bool FL, bool DB, bool XR>
 __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) double P[];
     const SmallNode nd = blockIdx.x < SMALL_INLINE_NODES ? a.inl[blockIdx.x] : a.nodes[blockIdx.x];
     const int n = a.n, NB = a.NB, NP = NB * SB, NBa = NB + 1;
     double* __restrict__ X = a.scratch + (long long)blockIdx.x * a.scratch_stride;     // finished columns
-    double* Cp = P;                       // current block column: slot (i - p) = block (i, p), i = p..NB
-    double* ldv = Cp + NBa * 256;         // diag(L)
-    double* fl = ldv + NP;                // FL: features [f][NP] then target [NP];  else: the block column's features [f][16]
+    double* C0 = P;                       // block column image(s): slot (i - p) = block (i, p), i = p..NB
+    double* ldv = C0 + (DB ? 2 : 1) * NBa * 256;   // diag(L)
+    double* xrow = ldv + NP;              // XR: [NB][256]
+    double* fl = xrow + (XR ? NB * 256 : 0);                // FL: features [f][NP] then target [NP];  else: the block column's features [f][16]
     double* featg = X + ((long long)NBa * (NBa + 1) / 2) * 256;                        // !FL: features [f][NP], target [NP]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: every branch on it is a scalar branch
-    const int li = lane & 15;
 
     {
         double* dstf = FL ? fl : featg;
@@ -395,8 +496,8 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
         for (int i = tid; i < NP; i += SM_THREADS) dstt[i] = (i < n) ? nd.target[i] : 0.0;
     }
     MidCtx mc;
-    mc.X = X; mc.Cp = Cp; mc.fl = fl; mc.featg = featg; mc.tgt = (FL ? fl : featg) + (long long)nd.nF * NP;
-    mc.n = n; mc.NB = NB; mc.NP = NP; mc.wave = wave; mc.lane = lane;
+    mc.X = X; mc.Cp = C0; mc.Cn = C0; mc.ldv = ldv; mc.Xrow = xrow; mc.tid = tid; mc.fl = fl; mc.featg = featg; mc.tgt = (FL ? fl : featg) + (long long)nd.nF * NP;
+    mc.n = n; mc.NB = NB; mc.NP = NP; mc.wave = wave; mc.lane = lane; mc.own = SM_WAVES - 1 - wave;
 #ifdef GPSLC_DIAG
     long long tt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     mc.tt = tt;
@@ -408,61 +509,27 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
     tt[7] = __builtin_amdgcn_s_memtime();
 #endif
 
-    for (int p = 0; p < NB; ++p) {
-        if (!FL) {
-            for (int idx = tid; idx < nd.nF * SB; idx += SM_THREADS) fl[idx] = featg[(idx >> 4) * NP + SB * p + (idx & 15)];
+    for (int p = -1; p < NB; ++p) {
+        const int q = p + 1;
+        // image of column p (factored in this step) / of column q (built in this step)
+        mc.Cp = C0 + ((DB && (p & 1)) ? NBa * 256 : 0);
+        mc.Cn = C0 + ((DB && (q & 1)) ? NBa * 256 : 0);
+        if (!FL && q < NB) {       // stage the features of block column q (read by mid_gram only, which nobody runs right now)
+            for (int idx = tid; idx < nd.nF * SB; idx += SM_THREADS) fl[idx] = featg[(idx >> 4) * NP + SB * q + (idx & 15)];
             __syncthreads();
         }
-        // ---- accumulate: block rows i = p + wave + 8u <= NB
-        mc.p = p;
-        const int nrows = (NB - p - wave >= 0) ? (NB - p - wave) / SM_WAVES + 1 : 0;     // scalar
+        // block rows of column q owned by this wave: i = q + own + 8u <= NB (none once q == NB)
+        const int span = NB - q - mc.own;
+        const int nrows = (q < NB && span >= 0) ? span / SM_WAVES + 1 : 0;               // scalar
         switch (nrows) {
-            case 1: mid_accumulate<1, FL>(nd, mc); break;
-            case 2: mid_accumulate<2, FL>(nd, mc); break;
-            case 3: mid_accumulate<3, FL>(nd, mc); break;
-            case 4: mid_accumulate<4, FL>(nd, mc); break;
-            case 5: mid_accumulate<5, FL>(nd, mc); break;
-            case 6: mid_accumulate<6, FL>(nd, mc); break;
-            default: break;
+            case 0: mid_step<0, FL, DB, XR>(nd, mc, p, bad); break;
+            case 1: mid_step<1, FL, DB, XR>(nd, mc, p, bad); break;
+            case 2: mid_step<2, FL, DB, XR>(nd, mc, p, bad); break;
+            case 3: mid_step<3, FL, DB, XR>(nd, mc, p, bad); break;
+            case 4: mid_step<4, FL, DB, XR>(nd, mc, p, bad); break;
+            case 5: mid_step<5, FL, DB, XR>(nd, mc, p, bad); break;
+            default: mid_step<6, FL, DB, XR>(nd, mc, p, bad); break;
         }
-        MID_STAMP(tt, 2);
-        __syncthreads();
-        MID_STAMP(tt, 3);
-        // ---- factor + panel on the LDS image of the column: rows below the diagonal block = 16 (NBa - p - 1); the
-        //      finished rows go straight from the registers to the scratch, for the columns to come
-        {
-            const int rows = SB * (NBa - p - 1);
-            for (int q0 = 0; q0 < rows; q0 += 48 * SM_WAVES) {
-                if (q0 + wave * 48 < rows) {                                 // scalar: this wave carries rows
-                    const bool is_diag = lane < SB;
-                    const int q = q0 + wave * 48 + (lane - SB);
-                    double r[SB];
-                    const double* src = nullptr;
-                    if (is_diag) src = Cp + li;
-                    else if (q < rows) src = Cp + (((q >> 4) + 1) << 8) + (q & 15);
-                    if (src) {
-#pragma unroll
-                        for (int c = 0; c < SB; ++c) r[c] = src[c * SB];
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < SB; ++c) r[c] = 0.0;
-                    }
-                    double lcc;
-                    sm_factor_rows(r, li, SB * p, bad, lcc);
-                    if (is_diag) {
-                        if (wave == 0 && q0 == 0) ldv[SB * p + li] = lcc;
-                    } else if (src) {
-                        double* dst = MBLK(p + 1 + (q >> 4), p) + (q & 15);
-#pragma unroll
-                        for (int c = 0; c < SB; ++c) dst[c * SB] = r[c];
-                    }
-                }
-            }
-        }
-        MID_STAMP(tt, 4);
-        __threadfence_block();
-        __syncthreads();
-        MID_STAMP(tt, 5);
     }
 #ifdef GPSLC_DIAG
     if (a.stamps && blockIdx.x == 0 && lane == 0)
@@ -495,32 +562,40 @@ size_t mid_gp_scratch_doubles(int n, int nF) {
     const long long NB = (n + SB - 1) / SB, NBa = NB + 1;
     return (size_t)(NBa * (NBa + 1) / 2 * 256 + (long long)(nF + 1) * NB * SB);
 }
-// LDS with the features resident (preferred) / staged per block column
-static size_t mid_lds_resident(int n, int nF) {
+// LDS: column image(s) + diag(L) [+ shared operand row] + the features resident (preferred) or staged per block column
+static size_t mid_lds(int n, int nF, bool resident, bool two_images, bool xrow) {
     const size_t NB = (n + SB - 1) / SB;
-    return ((NB + 1) * 256 + NB * SB + (size_t)(nF + 1) * NB * SB) * 8;
+    return ((two_images ? 2 : 1) * (NB + 1) * 256 + NB * SB + (xrow ? NB * 256 : 0) +
+            (resident ? (size_t)(nF + 1) * NB * SB : (size_t)nF * SB)) * 8;
 }
-static size_t mid_lds_staged(int n, int nF) {
-    const size_t NB = (n + SB - 1) / SB;
-    return ((NB + 1) * 256 + NB * SB + (size_t)nF * SB) * 8;
+static void mid_choose(int n, int nF, bool& resident, bool& two_images, bool& xrow) {
+    const size_t cap = 160 * 1024;
+    xrow = mid_lds(n, nF, true, true, true) <= cap;
+    two_images = xrow || mid_lds(n, nF, true, true, false) <= cap;
+    resident = two_images || mid_lds(n, nF, true, false, false) <= cap;
 }
 size_t mid_gp_lds_bytes(int n, int nF) {
-    const size_t r = mid_lds_resident(n, nF);
-    return r <= 160 * 1024 ? r : mid_lds_staged(n, nF);
+    bool r, d, x;
+    mid_choose(n, nF, r, d, x);
+    return mid_lds(n, nF, r, d, x);
 }
 bool mid_gp_fits(int n) { return (n + SB - 1) / SB + 1 <= SM_WAVES * MID_MAXI && n <= 640; }
 
-template <bool FL>
+template <bool FL, bool DB, bool XR>
 static void launch_mid_inst(const SmallArgs& a, int count, size_t bytes, hipStream_t st) {
     static DeviceOnce once;
-    lds_opt_in(once, (const void*)mid_gp_logpdf_kernel<FL>, 160 * 1024);
-    hipLaunchKernelGGL((mid_gp_logpdf_kernel<FL>), dim3(count), dim3(SM_THREADS), bytes, st, a);
+    lds_opt_in(once, (const void*)mid_gp_logpdf_kernel<FL, DB, XR>, 160 * 1024);
+    hipLaunchKernelGGL((mid_gp_logpdf_kernel<FL, DB, XR>), dim3(count), dim3(SM_THREADS), bytes, st, a);
 }
 
 void launch_mid_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st) {
-    const bool resident = mid_lds_resident(a.n, nF_max) <= 160 * 1024;
-    if (resident) launch_mid_inst<true>(a, count, mid_lds_resident(a.n, nF_max), st);
-    else launch_mid_inst<false>(a, count, mid_lds_staged(a.n, nF_max), st);
+    bool resident, two, xrow;
+    mid_choose(a.n, nF_max, resident, two, xrow);
+    const size_t bytes = mid_lds(a.n, nF_max, resident, two, xrow);
+    if (xrow) launch_mid_inst<true, true, true>(a, count, bytes, st);
+    else if (two) launch_mid_inst<true, true, false>(a, count, bytes, st);
+    else if (resident) launch_mid_inst<true, false, false>(a, count, bytes, st);
+    else launch_mid_inst<false, false, false>(a, count, bytes, st);
 }
 
 size_t small_gp_lds_bytes(int n, int nF) {

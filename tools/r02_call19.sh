@@ -1,0 +1,9 @@
+#!/bin/bash
+# mid-size node-score kernel: parity tests, per-wave clocks, latency, chain times
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r02_19
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout -k 10 400 python -m pytest tests/test_gpu_small_path.py tests/test_gpu_model_nodes.py tests/test_gpu_neec.py -m gpu -x -q > $OUT/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 $OUT/pytest.log
+[ $rc -eq 0 ] || exit 1
+timeout -k 10 100 python tools/mid_stamps.py 272 8 2>&1 | grep mid_gp
+timeout -k 10 300 python tools/bench_latency.py > $OUT/latency.log 2>&1; echo "lat rc=$?"; grep -E "n=(272|400|640)|gpslc" $OUT/latency.log
