@@ -901,8 +901,8 @@ int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* l
         static int printed = 0;
         const double* sp = hout + 4 * (size_t)count;
         if (printed++ < want_stamps)
-            fprintf(stderr, "small_gp stamps (shader clocks): inputs %.0f gram %.0f factor+panel %.0f update %.0f total %.0f\n",
-                    sp[0], sp[1], sp[2], sp[3], sp[5]);
+            fprintf(stderr, "small_gp stamps (shader clocks): inputs %.0f gram %.0f factor+panel %.0f (wave 0 inside the pivot chains: %.0f) update %.0f total %.0f\n",
+                    sp[0], sp[1], sp[2], sp[4], sp[3], sp[5]);
     }
     if (want_stamps && !in_lds) {      // node 0, per wave: cumulative shader clocks of the phases over all block columns
         static int printed = 0;

@@ -119,79 +119,110 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
         }
     }
     int bad = 0;
-    unsigned long long t_fac = 0, t_upd = 0, tq = 0;    // measurement build only
+    unsigned long long t_fac = 0, t_upd = 0, tq = 0, t_chain = 0;    // measurement build only
     __syncthreads();
     if (a.stamps) tq = __builtin_amdgcn_s_memtime();
     const unsigned long long t1 = tq;
 
-    for (int p = 0; p < NB; ++p) {
-        // ---- factor + panel: the column operations of chol(A_pp) on the diagonal block's rows (lanes 0-15 of every
-        // wave that carries rows) and on the rows below / the right-hand side (lanes 16-63: 48 rows per wave)
+    // ---- factor + panel of block column p: the column operations of chol(A_pp) on the diagonal block's rows (lanes 0-15
+    // of every wave that carries rows) and on the rows below / the right-hand side (lanes 16-63: 48 rows per wave)
+    auto factor_panel = [&](int p) {
+        const int rows = NP - SB * (p + 1);              // matrix rows below the block; row index `rows` = y
+        if (wave * 48 <= rows) {                         // scalar: this wave has rows to carry
+            const bool is_diag = lane < SB;
+            const int q = wave * 48 + (lane - SB);       // this lane's row below the block (lanes >= 16)
+            double r[SB];
+            double* dst = nullptr;                       // where this lane's row lives (null: nothing to carry)
+            if (is_diag) dst = SBLK(p, p) + li;
+            else if (q < rows) { const int gr = SB * (p + 1) + q; dst = SBLK(gr >> 4, p) + (gr & 15); }
+            const bool is_y = !is_diag && q == rows;
+            if (dst) {
+#pragma unroll
+                for (int c = 0; c < SB; ++c) r[c] = dst[c * SB];
+            } else if (is_y) {
+#pragma unroll
+                for (int c = 0; c < SB; ++c) r[c] = yv[SB * p + c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < SB; ++c) r[c] = 0.0;
+            }
+            double lcc;
+            sm_factor_rows(r, li, SB * p, bad, lcc);
+            if (is_diag) {
+                if (wave == 0) ldv[SB * p + li] = lcc;   // the factor's diagonal block itself is never read again
+            } else if (dst) {
+#pragma unroll
+                for (int c = 0; c < SB; ++c) dst[c * SB] = r[c];
+            } else if (is_y) {
+#pragma unroll
+                for (int c = 0; c < SB; ++c) zv[SB * p + c] = r[c];
+            }
+        }
+    };
+    // y_j[c] -= sum_k z_p[k] X_jp[c][k] for the entries q = first, first + step, ... of the blocks j = p + 1 + (q >> 4)
+    auto update_y = [&](int p, int first, int step, int q_begin, int q_end) {
+        for (int q = q_begin + first; q < q_end; q += step) {
+            const int j = p + 1 + (q >> 4), c = q & 15;
+            const double* X = SBLK(j, p);
+            double acc = yv[SB * j + c];
+#pragma unroll
+            for (int k = 0; k < SB; ++k) acc = fma(-zv[SB * p + k], X[k * SB + c], acc);
+            yv[SB * j + c] = acc;
+        }
+    };
+
+    // Right-looking with a one-column lookahead.  After column p is factored, only the blocks of column p + 1 (and the
+    // right-hand side entries of block p + 1) are brought up to date by everybody; then the waves that carry rows
+    // factor column p + 1 while the OTHER waves apply column p to the rest of the trailing matrix — the serial pivot
+    // chain of the next column runs under the bulk of this column's updates.
+    factor_panel(0);
+    __syncthreads();
+    if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_fac += t - tq; tq = t; }
+    for (int p = 0; p + 1 < NB; ++p) {
+        const int m = NB - p - 1;
+        // ---- blocks (p + 1 + ii, p + 1), ii < m: two independent blocks per wave and iteration (their MFMA chains interleave)
+        for (int t = wave; t < m; t += 2 * SM_WAVES) {
+            const int t2 = t + SM_WAVES;
+            if (t2 < m)
+                sm_update2(SBLK(p + 1 + t, p + 1), SBLK(p + 1 + t, p), SBLK(p + 1, p),
+                           SBLK(p + 1 + t2, p + 1), SBLK(p + 1 + t2, p), SBLK(p + 1, p), lane);
+            else
+                sm_update(SBLK(p + 1 + t, p + 1), SBLK(p + 1 + t, p), SBLK(p + 1, p), lane);
+        }
+        if (wave == SM_WAVES - 1) update_y(p, lane, 64, 0, SB);
+        __syncthreads();
+        if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_upd += t - tq; tq = t; }
+        // ---- factor + panel of column p + 1  ||  the rest of column p's trailing update: blocks (i, j), p + 2 <= j <= i
         {
-            const int rows = NP - SB * (p + 1);              // matrix rows below the block; row index `rows` = y
-            if (wave * 48 <= rows) {                         // wave-uniform: this wave has rows to carry
-                const bool is_diag = lane < SB;
-                const int q = wave * 48 + (lane - SB);       // this lane's row below the block (lanes >= 16)
-                double r[SB];
-                double* dst = nullptr;                       // where this lane's row lives (null: nothing to carry)
-                if (is_diag) dst = SBLK(p, p) + li;
-                else if (q < rows) { const int gr = SB * (p + 1) + q; dst = SBLK(gr >> 4, p) + (gr & 15); }
-                const bool is_y = !is_diag && q == rows;
-                if (dst) {
-#pragma unroll
-                    for (int c = 0; c < SB; ++c) r[c] = dst[c * SB];
-                } else if (is_y) {
-#pragma unroll
-                    for (int c = 0; c < SB; ++c) r[c] = yv[SB * p + c];
-                } else {
-#pragma unroll
-                    for (int c = 0; c < SB; ++c) r[c] = 0.0;
+            const int rows1 = NP - SB * (p + 2);
+            const int nc = min(SM_WAVES, rows1 / 48 + 1);               // waves that carry rows of column p + 1 (scalar)
+            const unsigned long long tf0 = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+            if (wave < nc) factor_panel(p + 1);
+            if (a.stamps) t_chain += __builtin_amdgcn_s_memtime() - tf0;
+            // the updaters: every wave that carries nothing (all of them, after their chains, should every wave carry)
+            const int u0 = nc == SM_WAVES ? 0 : nc;
+            if (wave >= u0) {
+                const int w = wave - u0, nw = SM_WAVES - u0;
+                const int m1 = m - 1, cnt = m1 * (m1 + 1) / 2;          // triangle over (ii, rem), 1 <= rem <= ii <= m - 1
+                for (int t = w; t < cnt; t += 2 * nw) {
+                    int ii = 0, rem = t;
+                    while (rem > ii) { rem -= ii + 1; ++ii; }
+                    const int bi = p + 2 + ii, bj = p + 2 + rem;
+                    const int t2 = t + nw;
+                    if (t2 < cnt) {
+                        int i2 = 0, rem2 = t2;
+                        while (rem2 > i2) { rem2 -= i2 + 1; ++i2; }
+                        sm_update2(SBLK(bi, bj), SBLK(bi, p), SBLK(bj, p),
+                                   SBLK(p + 2 + i2, p + 2 + rem2), SBLK(p + 2 + i2, p), SBLK(p + 2 + rem2, p), lane);
+                    } else {
+                        sm_update(SBLK(bi, bj), SBLK(bi, p), SBLK(bj, p), lane);
+                    }
                 }
-                double lcc;
-                sm_factor_rows(r, li, SB * p, bad, lcc);
-                if (is_diag) {
-                    if (wave == 0) ldv[SB * p + li] = lcc;   // the factor's diagonal block itself is never read again
-                } else if (dst) {
-#pragma unroll
-                    for (int c = 0; c < SB; ++c) dst[c * SB] = r[c];
-                } else if (is_y) {
-#pragma unroll
-                    for (int c = 0; c < SB; ++c) zv[SB * p + c] = r[c];
-                }
+                update_y(p, w * 64 + lane, nw * 64, SB, m * SB);
             }
         }
         __syncthreads();
         if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_fac += t - tq; tq = t; }
-        if (p + 1 >= NB) break;
-        // ---- trailing update: blocks (i, j), p < j <= i, dealt to the waves; right-hand side on the VALU
-        {
-            const int m = NB - p - 1;
-            const int nt_ = m * (m + 1) / 2;
-            // two independent blocks per wave and iteration: their MFMA chains interleave
-            for (int t = wave; t < nt_; t += 2 * SM_WAVES) {
-                int ii = 0, rem = t;
-                while (rem > ii) { rem -= ii + 1; ++ii; }
-                const int t2 = t + SM_WAVES;
-                if (t2 < nt_) {
-                    int i2 = 0, rem2 = t2;
-                    while (rem2 > i2) { rem2 -= i2 + 1; ++i2; }
-                    sm_update2(SBLK(p + 1 + ii, p + 1 + rem), SBLK(p + 1 + ii, p), SBLK(p + 1 + rem, p),
-                               SBLK(p + 1 + i2, p + 1 + rem2), SBLK(p + 1 + i2, p), SBLK(p + 1 + rem2, p), lane);
-                } else {
-                    sm_update(SBLK(p + 1 + ii, p + 1 + rem), SBLK(p + 1 + ii, p), SBLK(p + 1 + rem, p), lane);
-                }
-            }
-            for (int q = tid; q < m * SB; q += SM_THREADS) {     // y_j[c] -= sum_k z_p[k] X_jp[c][k]
-                const int j = p + 1 + (q >> 4), c = q & 15;
-                const double* X = SBLK(j, p);
-                double acc = yv[SB * j + c];
-#pragma unroll
-                for (int k = 0; k < SB; ++k) acc = fma(-zv[SB * p + k], X[k * SB + c], acc);
-                yv[SB * j + c] = acc;
-            }
-        }
-        __syncthreads();
-        if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_upd += t - tq; tq = t; }
     }
 
     if (wave == 0) {
@@ -214,7 +245,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
             if (a.stamps) {    // shader-clock ticks: inputs, Gram, factor+panel phases, update phases, -, total
                 double* sp = a.stamps + 8 * (long long)blockIdx.x;
                 sp[0] = (double)(t0 - tstart); sp[1] = (double)(t1 - t0); sp[2] = (double)t_fac; sp[3] = (double)t_upd;
-                sp[4] = 0.0; sp[5] = (double)(__builtin_amdgcn_s_memtime() - tstart);
+                sp[4] = (double)t_chain; sp[5] = (double)(__builtin_amdgcn_s_memtime() - tstart);
             }
         }
     }
