@@ -27,7 +27,7 @@
 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void diag_potrf_robust_kernel(TRef M, int k, int* info, int info_base, int info_div) {
-    extern __shared__ __attribute__((aligned(16))) double P[];        // 36 packed blocks
+    extern __shared__ __attribute__((aligned(16))) double P[];        // 36 packed blocks + [4 waves][16] broadcast lines
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: branches on it are scalar branches
     const int li = lane & 15;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void diag_potrf_robust_kernel(TRef M, int k, i
                 for (int c = 0; c < SB; ++c) r[c] = 0.0;
             }
             double lcc;
-            sm_factor_rows(r, li, SB * p, bad, lcc);
+            sm_factor_rows_lds(r, li, lane, SB * p, bad, lcc, P + 36 * 256 + wave * SB);
             if (is_diag) {
                 if (wave == 0) {                             // L_pp: lower triangle, exact diagonal, zeros above
 #pragma unroll
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void tile_trsm_robust_kernel(TRef X, TRef L, i
 }
 
 void launch_diag_robust(const TRef& M, int k, int* info, int info_base, int nbatch, hipStream_t st, int info_div) {
-    const int bytes = 36 * 256 * 8;
+    const int bytes = (36 * 256 + 4 * SB) * 8;
     static DeviceOnce once;
     lds_opt_in(once, (const void*)diag_potrf_robust_kernel, bytes);
     hipLaunchKernelGGL(diag_potrf_robust_kernel, dim3(nbatch), dim3(256), bytes, st, M, k, info, info_base, info_div < 1 ? 1 : info_div);

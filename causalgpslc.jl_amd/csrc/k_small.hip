@@ -53,7 +53,8 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
     double* yv = P + NBLK * 256;      // right-hand side, updated in place block by block
     double* zv = yv + NP;             // z = L^-1 target
     double* ldv = zv + NP;            // diag(L), for the log-determinant
-    double* fs = ldv + NP;            // scaled features, fs[f*NP + i] = F[i, f] * (1 / ls[f]) (scaled by the host)
+    double* bcl = ldv + NP;           // [8 waves][16]: multiplier broadcast lines of the pivot chains (sm_factor_rows_lds)
+    double* fs = bcl + SM_WAVES * SB; // scaled features, fs[f*NP + i] = F[i, f] * (1 / ls[f]) (scaled by the host)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: branches on it are scalar branches
     const int li = lane & 15;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
                 for (int c = 0; c < SB; ++c) r[c] = 0.0;
             }
             double lcc;
-            sm_factor_rows(r, li, SB * p, bad, lcc);
+            sm_factor_rows_lds(r, li, lane, SB * p, bad, lcc, bcl + wave * SB);
             if (is_diag) {
                 if (wave == 0) ldv[SB * p + li] = lcc;   // the factor's diagonal block itself is never read again
             } else if (dst) {
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
 // Every wave owns up to MID_MAXI block rows of a column and keeps their 16 x 16 blocks in MFMA accumulators from the
 // Gram evaluation to the hand-over to the factorisation.  Step p of the main loop, two barriers:
 //   phase B   waves that carry rows: factor + panel of column p — exactly the register-resident column operations of the
-//             small kernel (sm_factor_rows) on the LDS image of the column, 48 rows per wave; the finished rows go
+//             small kernel (sm_factor_rows_lds) on the LDS image of the column, 48 rows per wave; the finished rows go
 //             from the registers straight to the scratch.
 //             EVERY wave, for its rows of column p + 1: Gram blocks straight into the accumulator layout, then
 //             -= sum_{k<p} X(i,k) X(p+1,k)^T  (operand fragments: 512-byte coalesced reads of the scratch through a
@@ -282,6 +283,7 @@ struct MidCtx {
     double* Cp;             // LDS image of the block column being factored: slot (i - p) = block (i, p)
     double* Cn;             // LDS image of the next block column under construction (== Cp without the second buffer)
     double* ldv;            // LDS: diag(L)
+    double* bc;             // LDS: this wave's 16-double multiplier broadcast line (sm_factor_rows_lds)
     double* Xrow;           // LDS (XR): the finished blocks X(q, 0 .. q-2) of the block row the next k loop shares
     const double* fl;       // LDS features (FL: [f][NP]; else the block column's [f][16])
     const double* featg;    // !FL: features in the scratch [f][NP]
@@ -424,7 +426,7 @@ __device__ __forceinline__ void mid_factor(const MidCtx& c, int p, int& bad) {
                 for (int cc = 0; cc < SB; ++cc) r[cc] = 0.0;
             }
             double lcc;
-            sm_factor_rows(r, li, SB * p, bad, lcc);
+            sm_factor_rows_lds(r, li, lane, SB * p, bad, lcc, c.bc);
             if (is_diag) {
                 if (wave == 0 && q0 == 0) c.ldv[SB * p + li] = lcc;
             } else if (src) {
@@ -510,7 +512,8 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
     double* __restrict__ X = a.scratch + (long long)blockIdx.x * a.scratch_stride;     // finished columns
     double* C0 = P;                       // block column image(s): slot (i - p) = block (i, p), i = p..NB
     double* ldv = C0 + (DB ? 2 : 1) * NBa * 256;   // diag(L)
-    double* xrow = ldv + NP;              // XR: [NB][256]
+    double* bcl = ldv + NP;               // [8 waves][16] multiplier broadcast lines
+    double* xrow = bcl + SM_WAVES * SB;   // XR: [NB][256]
     double* fl = xrow + (XR ? NB * 256 : 0);                // FL: features [f][NP] then target [NP];  else: the block column's features [f][16]
     double* featg = X + ((long long)NBa * (NBa + 1) / 2) * 256;                        // !FL: features [f][NP], target [NP]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
         for (int i = tid; i < NP; i += SM_THREADS) dstt[i] = (i < n) ? nd.target[i] : 0.0;
     }
     MidCtx mc;
-    mc.X = X; mc.Cp = C0; mc.Cn = C0; mc.ldv = ldv; mc.Xrow = xrow; mc.tid = tid; mc.fl = fl; mc.featg = featg; mc.tgt = (FL ? fl : featg) + (long long)nd.nF * NP;
+    mc.X = X; mc.Cp = C0; mc.Cn = C0; mc.ldv = ldv; mc.Xrow = xrow; mc.tid = tid; mc.bc = bcl + wave * SB; mc.fl = fl; mc.featg = featg; mc.tgt = (FL ? fl : featg) + (long long)nd.nF * NP;
     mc.n = n; mc.NB = NB; mc.NP = NP; mc.wave = wave; mc.lane = lane; mc.own = SM_WAVES - 1 - wave;
 #ifdef GPSLC_DIAG
     long long tt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -596,7 +599,7 @@ size_t mid_gp_scratch_doubles(int n, int nF) {
 // LDS: column image(s) + diag(L) [+ shared operand row] + the features resident (preferred) or staged per block column
 static size_t mid_lds(int n, int nF, bool resident, bool two_images, bool xrow) {
     const size_t NB = (n + SB - 1) / SB;
-    return ((two_images ? 2 : 1) * (NB + 1) * 256 + NB * SB + (xrow ? NB * 256 : 0) +
+    return ((two_images ? 2 : 1) * (NB + 1) * 256 + NB * SB + SM_WAVES * SB + (xrow ? NB * 256 : 0) +
             (resident ? (size_t)(nF + 1) * NB * SB : (size_t)nF * SB)) * 8;
 }
 static void mid_choose(int n, int nF, bool& resident, bool& two_images, bool& xrow) {
@@ -631,7 +634,7 @@ void launch_mid_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st) {
 
 size_t small_gp_lds_bytes(int n, int nF) {
     const int NB = (n + SB - 1) / SB, NP = NB * SB;
-    return ((size_t)(NB * (NB + 1) / 2) * 256 + 3 * (size_t)NP + (size_t)nF * NP) * 8;
+    return ((size_t)(NB * (NB + 1) / 2) * 256 + 3 * (size_t)NP + SM_WAVES * SB + (size_t)nF * NP) * 8;
 }
 
 void launch_small_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st) {

@@ -120,7 +120,7 @@ int gpslc_gp_logpdf(gpslc_ctx* ctx, int64_t S, int32_t nF, const double* F, int3
  * call — what one Gen `update` re-scores (src/model.jl:11-131): the nX `:X => k => :X` nodes, `:T` / `:logitT` and
  * `:Y` (F = [U | X | T], ls = [uyLS ; xyLS ; tyLS]) of a proposal, or the nodes of several proposals at once.
  * logpdf[i] = log N(target_i; 0, scale_i * exp.(rbfKernelLog(F_i, F_i, ls_i)) + noise_i * I); host pointers.
- * While the n x n matrix fits one CU's LDS (n <= 160 for any nF <= 32, up to n = 176 for nF <= 17) ALL nodes are
+ * While the n x n matrix fits one CU's LDS (n <= 160 for any nF <= 32, up to n = 176 for nF <= 16) ALL nodes are
  * scored by ONE kernel launch, one workgroup per node (Gram build, Cholesky, forward solve and reductions never
  * leave the CU); gpslc_gp_logpdf and gpslc_y_logpdf take the same path at those sizes.  Larger n: the general
  * tiled path, node by node.  Return value and gpslc_last_info (count entries) as for gpslc_gp_logpdf. */

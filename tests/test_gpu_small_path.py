@@ -27,7 +27,7 @@ def test_heterogeneous_nodes_one_call(gp, n):
     rng = np.random.default_rng(1000 + n)
     ctx = gp.Context(n, 0, 0)
     nodes = []
-    for nF in (0, 1, 3, 8, 17):
+    for nF in (0, 1, 3, 8, 16):
         F = None if nF == 0 else rng.standard_normal((n, nF))
         ls = None if nF == 0 else rng.uniform(0.6, 2.0, nF)
         nodes.append((F, ls, rng.uniform(0.5, 2.0), rng.uniform(0.3, 1.5), rng.standard_normal(n)))
