@@ -142,6 +142,9 @@ __global__ __launch_bounds__(256) void tile_trsm_robust_kernel(TRef X, TRef L, i
 #pragma unroll
             for (int v = 0; v < 4; ++v) Bp[(lg + 4 * v) * SB + li] = acc[v];
         }
+        // the wave's lanes hand data to one another through its private part of XB without a barrier: LDS executes a
+        // wave's operations in order, the wavefront-scope fence (no instruction) makes the compiler honour that order
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // solve with L_pp: lanes 0-15 = rows of L_pp, lanes 16-31 = rows of block (wave, p), lanes 32-47 = rows of
         // block (wave + 4, p)
         {
@@ -168,6 +171,7 @@ __global__ __launch_bounds__(256) void tile_trsm_robust_kernel(TRef X, TRef L, i
                 for (int c = 0; c < SB; ++c) src[c * SB] = r[c];
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     __syncthreads();
     {

@@ -196,10 +196,12 @@ class _RealTChain:
     def _t_features(self, U=None, v=None):
         """Features and lengthscales of the :T / :logitT node: [U, X], [U], [X] or nothing (T ~ N(0, I))."""
         v = v or self.v
-        cols = ([self._umodel(U)] if self.nU else []) + ([self.X] if self.nX else [])
         ls = ([v["utLS"]] if self.nU else []) + ([v["xtLS"]] if self.nX else [])
-        if not cols:
+        if not ls:
             return np.zeros((self.n, 0)), np.zeros(0)
+        if U is None:
+            return self._cur()["Ft"], np.concatenate(ls)
+        cols = ([self._umodel(U)] if self.nU else []) + ([self.X] if self.nX else [])
         return np.column_stack(cols), np.concatenate(ls)
 
     def _t_cov(self):
@@ -248,7 +250,22 @@ class _RealTChain:
         return float(np.sum(api.mvnLogpdf(None, np.column_stack(U), covscale=np.full(self.nU, un), ctx=self.ctx)))
 
     def _umodel(self, U=None):
-        return toMatrixModel(self.U if U is None else U, self.n, self.nU)
+        if U is None:
+            return self._cur()["Um"]
+        return toMatrixModel(U, self.n, self.nU)
+
+    def _cur(self):
+        """Feature blocks of the CURRENT latent state — the model-side U matrix, the :T node's [U | X] and the :Y node's
+        [U | X | T], Fortran-ordered as the C ABI wants them — built once per value of self.U (the hyper-parameter
+        sweeps score dozens of proposals on the same U; a slice move replaces the list self.U)."""
+        c = getattr(self, "_cur_cache", None)
+        if c is None or c["key"] is not self.U:
+            Um = toMatrixModel(self.U, self.n, self.nU) if self.nU else None
+            tx = ([Um] if self.nU else []) + ([self.X] if self.nX else [])
+            Ft = np.asfortranarray(np.column_stack(tx)) if tx else np.zeros((self.n, 0))
+            Fy = np.asfortranarray(np.column_stack(tx + [self.T]))
+            c = self._cur_cache = {"key": self.U, "Um": Um, "Ft": Ft, "Fy": Fy}
+        return c
 
     def _uxls_model(self, v):
         """`toMatrix(uxLS, nX, nU)` of src/model_prior.jl:110 -> (nX, nU); row k feeds X node k."""
@@ -394,9 +411,8 @@ class _RealTChain:
         if pr["node"] == "t":
             F, ls = self._t_features(None, v2)
             return (F, ls, v2["tScale"], v2["tNoise"], self.logitT if self.binary else self.T)
-        cols = ([self._umodel()] if self.nU else []) + ([self.X] if self.nX else []) + [self.T]
         ls = np.concatenate(([v2["uyLS"]] if self.nU else []) + ([v2["xyLS"]] if self.nX else []) + [[v2["tyLS"]]])
-        return (np.column_stack(cols), ls, v2["yScale"], v2["yNoise"], self.Y)
+        return (self._cur()["Fy"], ls, v2["yScale"], v2["yNoise"], self.Y)
 
     def mh_batch(self, addrs, draws=None):
         """MH moves on addresses that touch DIFFERENT nodes, scored in one fused call (gpslc_nodes_logpdf: one
