@@ -296,10 +296,9 @@ class _RealTChain:
         ls = np.concatenate(([v["uyLS"]] if self.nU else []) + ([v["xyLS"]] if self.nX else []) + [[v["tyLS"]]])
         return float(api.gpLogpdf(np.column_stack(cols), ls, v["yScale"], v["yNoise"], self.Y, ctx=self.ctx)[0])
 
-    def score_xty(self, v=None, U=None):
-        """Every node a move of U touches — the nX `:X => k => :X` nodes, `:T` / `:logitT` and `:Y` — in ONE fused
-        call (gpslc_nodes_logpdf): what a Gen `update` of `:U => k => :U` re-scores (src/inference.jl:48-54)."""
-        v = v or self.v
+    def _xty_nodes(self, v, U):
+        """Node descriptors of everything a move of U touches: the nX `:X => k => :X` nodes, `:T` / `:logitT` (when
+        something feeds it) and `:Y`.  Returns (nodes, nx, has_t)."""
         nodes = []
         Um = self._umodel(U) if self.nU else None
         nx = self.nX if (self.nX and self.nU) else 0
@@ -312,13 +311,39 @@ class _RealTChain:
         has_t = Ft.shape[1] > 0
         if has_t:
             nodes.append((Ft, lst, v["tScale"], v["tNoise"], target))
-        cols = ([Um] if self.nU else []) + ([self.X] if self.nX else []) + [self.T]
+        if U is None:
+            Fy = self._cur()["Fy"]
+        else:
+            Fy = np.column_stack(([Um] if self.nU else []) + ([self.X] if self.nX else []) + [self.T])
         lsy = np.concatenate(([v["uyLS"]] if self.nU else []) + ([v["xyLS"]] if self.nX else []) + [[v["tyLS"]]])
-        nodes.append((np.column_stack(cols), lsy, v["yScale"], v["yNoise"], self.Y))
-        out = api.nodesLogpdf(nodes, self.ctx)
-        sx = out[:nx].copy()
+        nodes.append((Fy, lsy, v["yScale"], v["yNoise"], self.Y))
+        return nodes, nx, has_t
+
+    def _xty_split(self, out, nx, has_t):
+        target = self.logitT if self.binary else self.T
+        sx = np.array(out[:nx], dtype=np.float64)
         st = float(out[nx]) if has_t else float(-0.5 * (target @ target) - 0.5 * self.n * math.log(2.0 * math.pi))
         return sx, st, float(out[-1])
+
+    def score_xty(self, v=None, U=None):
+        """Every node a move of U touches — the nX `:X => k => :X` nodes, `:T` / `:logitT` and `:Y` — in ONE fused
+        call (gpslc_nodes_logpdf): what a Gen `update` of `:U => k => :U` re-scores (src/inference.jl:48-54)."""
+        v = v or self.v
+        nodes, nx, has_t = self._xty_nodes(v, U)
+        return self._xty_split(api.nodesLogpdf(nodes, self.ctx), nx, has_t)
+
+    def score_xty_many(self, Us, v=None):
+        """The same for several candidate values of U in ONE fused call (len(Us) x (nX + 2) nodes, one workgroup each);
+        a candidate with a covariance that is not positive definite scores -inf on that node.  Returns a list of
+        (s_x, s_t, s_y)."""
+        v = v or self.v
+        allnodes, per = [], 0
+        for U in Us:
+            nodes, nx, has_t = self._xty_nodes(v, U)
+            per = len(nodes)
+            allnodes += nodes
+        out = api.nodesLogpdf(allnodes, self.ctx, fail_value=-math.inf)
+        return [self._xty_split(out[i * per:(i + 1) * per], nx, has_t) for i in range(len(Us))]
 
     # which node an address touches
     TOUCH = {"uNoise": "u", "tNoise": "t", "yNoise": "y", "tyLS": "y", "tScale": "t", "yScale": "y",
@@ -332,15 +357,17 @@ class _RealTChain:
         sh, sc = _proposal_params(cur, self.pp["drift"])
         return sc / self.rng.gamma(sh), math.log(self.rng.random())
 
-    def _propose(self, name, i=None, j=None, draw=None):
-        """The proposal half of one `mh(trace, paramProposal, (drift, addr))`."""
-        cur = self.v[name] if i is None else (self.v[name][i] if j is None else self.v[name][i][j])
+    def _propose(self, name, i=None, j=None, draw=None, base=None):
+        """The proposal half of one `mh(trace, paramProposal, (drift, addr))`.  ``base``: the parameter values the move
+        starts from (default: the current state; a speculated state in `mh_speculative`)."""
+        vb = self.v if base is None else base
+        cur = vb[name] if i is None else (vb[name][i] if j is None else vb[name][i][j])
         sh, sc = _proposal_params(cur, self.pp["drift"])
         new, log_unif = draw if draw is not None else self._draw(name, i, j)
         shb, scb = _proposal_params(new, self.pp["drift"])
-        v2 = dict(self.v)
+        v2 = dict(vb)
         if i is not None:
-            arr = self.v[name].copy()
+            arr = vb[name].copy()
             if j is None:
                 arr[i] = new
             else:
@@ -439,31 +466,110 @@ class _RealTChain:
             acc += self._decide(p_, new_s)
         return acc
 
-    def elliptical_slice(self, k):
-        """`elliptical_slice(trace, :U => k => :U, zeros(n), uCov)` (src/inference.jl:48-54, :92-98)."""
-        nu = math.sqrt(self.v["uNoise"]) * (self.Lsig @ self.rng.standard_normal(self.n))
-        log_y = float(np.sum(self.s_x)) + self.s_t + self.s_y + math.log(self.rng.random())
-        theta = self.rng.uniform(0.0, 2.0 * math.pi)
+    def mh_speculative(self, segments, draws):
+        """Several consecutive MH moves of every per-node address chain in ONE fused call.  For a segment a_0 .. a_{D-1}
+        of a chain the proposal of a_l is scored under every accept / reject outcome of a_0 .. a_{l-1} (2^D - 1 nodes
+        per chain: an accepted move changes the parameters the next one starts from); the outcomes are then decided in
+        order with the pre-drawn uniforms, each against the score its predecessor left — the decisions, and therefore
+        the chain, are those of the one-move-at-a-time schedule, in ceil(len / D) launches instead of len."""
+        nodes, index, plans = [], {}, []
+        for seg in segments:
+            tree = {}
+
+            def build(level, prefix, base):
+                a = seg[level]
+                pr = self._propose(*(tuple(a) + (None,) * (3 - len(a))), draw=draws[a], base=base)
+                tree[prefix] = pr
+                if pr["node"] != "u":
+                    index[id(pr)] = len(nodes)
+                    nodes.append(self._gp_node(pr))
+                if level + 1 < len(seg):
+                    build(level + 1, prefix + (0,), base)
+                    build(level + 1, prefix + (1,), pr["v2"])
+
+            build(0, (), self.v)
+            plans.append((seg, tree))
+        out = api.nodesLogpdf(nodes, self.ctx, fail_value=-math.inf) if nodes else []
+        acc = 0
+        for seg, tree in plans:
+            prefix = ()
+            for _ in seg:
+                pr = tree[prefix]
+                if pr["node"] == "u":
+                    try:
+                        new_s = self.score_u(uNoise=pr["new"])
+                    except api.PosDefException:
+                        new_s = -math.inf
+                else:
+                    new_s = float(out[index[id(pr)]])
+                ok = self._decide(pr, new_s)
+                acc += ok
+                prefix += (1 if ok else 0,)
+        return acc
+
+    mh_depth = 2        # consecutive moves of a chain scored speculatively per fused call (2^depth - 1 nodes per chain)
+
+    slice_depth = 8     # candidates of a slice's all-rejected path scored per fused call
+
+    def elliptical_slice(self, k, depth=None):
+        """`elliptical_slice(trace, :U => k => :U, zeros(n), uCov)` (src/inference.jl:48-54, :92-98).
+        The shrinking bracket depends only on the angles tried, not on their scores: the first ``depth`` candidates of
+        the all-rejected path are therefore known up front and are scored in ONE fused call (depth x (nX + 2) nodes, one
+        workgroup each); the first one above the slice level is the move, exactly as if they had been tried one by
+        one — the generator is rewound to where the one-by-one loop would have left it, so ``depth`` changes the number
+        of launches (≈ 10 tries per slice on IHDP), not the chain.  ``depth=1`` is the reference's schedule."""
+        rng = self.rng
+        depth = self.slice_depth if depth is None else depth
+        nu = math.sqrt(self.v["uNoise"]) * (self.Lsig @ rng.standard_normal(self.n))
+        log_y = float(np.sum(self.s_x)) + self.s_t + self.s_y + math.log(rng.random())
+        theta = rng.uniform(0.0, 2.0 * math.pi)
         lo, hi = theta - 2.0 * math.pi, theta
         f = self.U[k]
-        for _ in range(200):
-            prop = f * math.cos(theta) + nu * math.sin(theta)
-            U2 = list(self.U)
-            U2[k] = prop
-            try:
-                sx, st, sy = self.score_xty(U=U2)
-            except api.PosDefException:
-                sx, st, sy = np.zeros(0), -math.inf, -math.inf
-            if float(np.sum(sx)) + st + sy > log_y:
-                self.U, self.s_x, self.s_t, self.s_y = U2, sx, st, sy
-                self.s_u = self.score_u()
-                return
-            if theta < 0:
-                lo = theta
+        tries = 0
+        while tries < 200:
+            d = max(1, min(depth, 200 - tries))
+            state = rng.bit_generator.state            # generator right after `theta` was drawn
+            thetas, brackets = [theta], []
+            t, l, h = theta, lo, hi
+            for _ in range(d - 1):                     # the path taken if every candidate so far is rejected
+                if t < 0:
+                    l = t
+                else:
+                    h = t
+                brackets.append((l, h))
+                t = rng.uniform(l, h)
+                thetas.append(t)
+            cands = []
+            for t in thetas:
+                U2 = list(self.U)
+                U2[k] = f * math.cos(t) + nu * math.sin(t)
+                cands.append(U2)
+            scores = self.score_xty_many(cands) if d > 1 else [self._score_xty_or_inf(cands[0])]
+            for j, (sx, st, sy) in enumerate(scores):
+                if float(np.sum(sx)) + st + sy > log_y:
+                    rng.bit_generator.state = state    # rewind, then consume exactly the j draws the one-by-one loop made
+                    for (l, h) in brackets[:j]:
+                        rng.uniform(l, h)
+                    self.U, self.s_x, self.s_t, self.s_y = cands[j], sx, st, sy
+                    self.s_u = self.score_u()
+                    return
+            # all d rejected: shrink past the last one and go on
+            t = thetas[-1]
+            if brackets:
+                lo, hi = brackets[-1]
+            if t < 0:
+                lo = t
             else:
-                hi = theta
-            theta = self.rng.uniform(lo, hi)
+                hi = t
+            theta = rng.uniform(lo, hi)
+            tries += d
         # bracket collapsed onto the current state: keep it
+
+    def _score_xty_or_inf(self, U2):
+        try:
+            return self.score_xty(U=U2)
+        except api.PosDefException:
+            return np.zeros(0), -math.inf, -math.inf
 
     def sweep_addresses(self):
         """The addresses of one inner sweep in the reference's order (src/inference.jl:23-44 / :78-89 with U,
@@ -482,7 +588,7 @@ class _RealTChain:
                 out += [("xtLS", k), ("xyLS", k)]
         return out + [("tScale",), ("yScale",)]
 
-    def sweep_mh(self, batched=True):
+    def sweep_mh(self, batched=True, depth=None):
         """One inner sweep.  ``batched=False``: address by address, one score call each — the reference's schedule.
         ``batched=True`` (default): the sweep is split into its per-node address chains (the :Y chain yNoise, tyLS,
         uyLS.., xyLS.., yScale; the :T chain; one chain per :X => k => :X; uNoise for the U prior), each kept in
@@ -490,7 +596,10 @@ class _RealTChain:
         calls per sweep instead of one per address (IHDP, nU = 1, nX = 6: 10 instead of 38).  Moves on different
         nodes commute (see `mh_batch`), so this is the same transition kernel — and since an address's random
         numbers depend only on its own current value, they are drawn up front in the reference's address order:
-        both schedules produce the SAME chain, bit for bit (tests/test_gpu_neec.py)."""
+        both schedules produce the SAME chain, bit for bit (tests/test_gpu_neec.py).  ``depth`` (default `mh_depth`)
+        consecutive moves of every chain are scored per call under all their accept / reject outcomes
+        (`mh_speculative`): 5 launches per IHDP sweep at the default depth 2 (deeper trees cost more host staging than
+        they save in launches: tools/bench_slice_depth.py)."""
         addrs = self.sweep_addresses()
         draws = {a: self._draw(*a) for a in addrs}
         if not batched:
@@ -502,8 +611,13 @@ class _RealTChain:
             node = self.TOUCH[a[0]]
             key = (node, (a[2] if a[0] == "uxLS" else a[1]) if node == "x" else None)
             chains.setdefault(key, []).append(a)
-        for t in range(max(len(c) for c in chains.values())):
-            self.mh_batch([c[t] for c in chains.values() if t < len(c)], draws)
+        d = max(1, int(self.mh_depth if depth is None else depth))
+        for t in range(0, max(len(c) for c in chains.values()), d):
+            segs = [c[t:t + d] for c in chains.values() if t < len(c)]
+            if d == 1:
+                self.mh_batch([sg[0] for sg in segs], draws)
+            else:
+                self.mh_speculative(segs, draws)
 
     def snapshot(self):
         out = {k: (val.copy() if isinstance(val, np.ndarray) else val) for k, val in self.v.items()}

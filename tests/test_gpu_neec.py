@@ -201,7 +201,10 @@ def test_documented_example_workflow_runs(gp):
 def test_batched_sweep_is_the_sequential_sweep(gp, data, nU, binary):
     """`sweep_mh(batched=True)` scores step t of every per-node address chain in one fused call; moves on different
     nodes commute and an address's random numbers are drawn up front in the reference's address order, so the chain
-    is the one the address-by-address schedule (src/inference.jl:23-44) produces — bit for bit."""
+    is the one the address-by-address schedule (src/inference.jl:23-44) produces — bit for bit, also when several
+    consecutive moves of a chain are scored speculatively under all their accept / reject outcomes.  The same holds for the
+    elliptical slice that scores the first 8 candidates of its all-rejected path in one call and rewinds the generator
+    to where the one-by-one loop would have left it."""
     from causalgpslc_jl_amd import inference as inf
     SigmaU, obj, X, T, Y = gp.prepareData(os.path.join(GOLD, data), 1e-6)
     pp = gp.getPriorParameters()
@@ -209,11 +212,14 @@ def test_batched_sweep_is_the_sequential_sweep(gp, data, nU, binary):
     snaps = []
     for batched in (False, True):
         ch = inf._RealTChain(pp, SigmaU, X, T, Y, nU, np.random.Generator(np.random.Philox(5)), binary=binary)
-        for _ in range(3):
-            ch.sweep_mh(batched=batched)
+        for it in range(3):
+            # speculative depth 2 (the default), 3 and 1 (one move of every chain per call) against address by address
+            ch.sweep_mh(batched=batched, depth=(2, 3, 1)[it])
             if binary:
                 ch.elliptical_slice_logitT()
-            ch.elliptical_slice(0)
+            for k in range(nU):
+                # the slice too: candidates of the all-rejected path scored 8 at a time vs one by one (depth = 1)
+                ch.elliptical_slice(k, depth=8 if batched else 1)
         snaps.append((ch.snapshot(), ch.s_x.copy(), ch.s_t, ch.s_y, ch.s_u))
     a, b = snaps
     for k in a[0]:
