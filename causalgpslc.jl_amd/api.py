@@ -516,23 +516,36 @@ def nodesLogpdf(nodes, ctx: Context, fail_value=None):
     cnt = len(nodes)
     arr = (_lib.Node * max(cnt, 1))()
     keep = []
+    memo = {}          # nodes of one call share arrays (the same feature block under several parameter values, one target)
+
+    def conv(a, shape=None):
+        key = id(a)
+        hit = memo.get(key)
+        if hit is None:
+            b = _f(a, shape)
+            if b.ndim == 1 and shape is None:
+                b = b[:, None]
+            hit = memo[key] = (b, b.ctypes.data)
+            keep.append(a)
+        return hit
+
     for i, (F, LS, scale, noise, target) in enumerate(nodes):
-        tg = _f(target, (ctx.n,))
-        if F is None or np.asarray(F).size == 0:
-            Fa, ls, nF = None, None, 0
+        tg, tgp = conv(target, (ctx.n,))
+        if F is None or (isinstance(F, np.ndarray) and F.size == 0) or (not isinstance(F, np.ndarray) and np.asarray(F).size == 0):
+            Fp, lsp, nF = None, None, 0
         else:
-            Fa = _f(F)
-            if Fa.ndim == 1:
-                Fa = Fa[:, None]
+            Fa, Fp = conv(F)
             nF = Fa.shape[1]
-            ls = np.ascontiguousarray(np.asarray(LS, dtype=np.float64).reshape(nF))
-        keep.append((Fa, ls, tg))
-        arr[i].nF = nF
-        arr[i].F = None if Fa is None else Fa.ctypes.data
-        arr[i].ls = None if ls is None else ls.ctypes.data
-        arr[i].scale = float(scale)
-        arr[i].noise = float(noise)
-        arr[i].target = tg.ctypes.data
+            ls = np.ascontiguousarray(LS, dtype=np.float64).reshape(nF)
+            keep.append(ls)
+            lsp = ls.ctypes.data
+        nd = arr[i]
+        nd.nF = nF
+        nd.F = Fp
+        nd.ls = lsp
+        nd.scale = float(scale)
+        nd.noise = float(noise)
+        nd.target = tgp
     out = np.empty(cnt)
     st = ctx.lib.gpslc_nodes_logpdf(ctx.h, cnt, C.cast(arr, C.c_void_p), _p(out))
     if st > 0 and fail_value is not None:
