@@ -243,11 +243,26 @@ class _RealTChain:
 
     # ---- node scores (GPU) ------------------------------------------------------------------------
     def score_u(self, uNoise=None, U=None):
+        """sum_k log N(U_k; 0, uNoise * SigmaU) (generateUfromSigmaU, src/model_likelihood.jl:4-10).  With
+        Sigma = SigmaU fixed for the data set, log N(x; 0, c Sigma) = -(n log 2 pi + n log c + logdet Sigma + q / c) / 2
+        with q = x' Sigma^-1 x: the GPU is asked once per value of U (covscale = 1, cached factor of SigmaU) for the
+        quadratic forms, and a move of uNoise alone — one per sweep — is scored on the host from them."""
         if not self.nU:
             return 0.0
-        U = self.U if U is None else U
         un = self.v["uNoise"] if uNoise is None else uNoise
-        return float(np.sum(api.mvnLogpdf(None, np.column_stack(U), covscale=np.full(self.nU, un), ctx=self.ctx)))
+        n, l2pi = self.n, math.log(2.0 * math.pi)
+        if getattr(self, "_ld_sigma", None) is None:        # logdet SigmaU from the score of x = 0
+            self._ld_sigma = -2.0 * float(api.mvnLogpdf(None, np.zeros((n, 1)), covscale=np.ones(1), ctx=self.ctx)[0]) - n * l2pi
+        Ucur = self.U if U is None else U
+        c = getattr(self, "_q_cache", None)
+        if U is not None or c is None or c[0] is not self.U:
+            lp1 = api.mvnLogpdf(None, np.column_stack(Ucur), covscale=np.ones(self.nU), ctx=self.ctx)
+            q = -2.0 * lp1 - n * l2pi - self._ld_sigma
+            if U is None:
+                self._q_cache = (self.U, q)
+        else:
+            q = c[1]
+        return float(np.sum(-0.5 * (n * l2pi + n * math.log(un) + self._ld_sigma + q / un)))
 
     def _umodel(self, U=None):
         if U is None:

@@ -103,6 +103,11 @@ def test_full_model_chain_scores_are_consistent(gp):
     after = ch.snapshot()
     assert any(not np.array_equal(before[k], after[k]) for k in ("uxLS", "xNoise", "xtLS", "xyLS", "xScale"))
     assert np.allclose(ch.s_x, ch.score_x(), rtol=1e-12) and len(ch.s_x) == 3
+    # the U prior: score_u evaluates moves of uNoise on the host from the cached quadratic forms U_k' SigmaU^-1 U_k
+    from causalgpslc_jl_amd import api
+    for un in (ch.v["uNoise"], 0.37, 5.0):
+        direct = float(np.sum(api.mvnLogpdf(None, np.column_stack(ch.U), covscale=np.full(2, un), ctx=ch.ctx)))
+        assert np.isclose(ch.score_u(uNoise=un), direct, rtol=1e-10), (un, ch.score_u(uNoise=un), direct)
     assert np.isclose(ch.s_t, ch.score_t(), rtol=1e-12) and np.isclose(ch.s_y, ch.score_y(), rtol=1e-12)
     # model-side reshape of uxLS (src/model_prior.jl:110): nU traced vectors of length nX -> (nX, nU), interleaved
     v = {"uxLS": np.array([[1.0, 2.0, 3.0], [10.0, 20.0, 30.0]])}
