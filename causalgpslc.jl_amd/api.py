@@ -505,18 +505,13 @@ def gpLogpdf(F, LS, scale, noise, target, ctx: Optional[Context] = None):
     return out
 
 
-def nodesLogpdf(nodes, ctx: Context, fail_value=None):
-    """The fused whole-model score (gpslc_nodes_logpdf): ``nodes`` is a sequence of (F, LS, scale, noise, target)
-    — F (n, nF) or None, LS (nF,), scalars, target (n,) — one per Gen address to re-score (:X => k => :X, :T /
-    :logitT, :Y with F = [U | X | T]; src/model_likelihood.jl:13-120).  One call, and for n <= 640 one kernel
-    launch, whatever the nodes' feature counts.  Returns the log-densities (len(nodes),).
-    A covariance that is not positive definite raises PosDefException (PDMats' behaviour inside Gen's mvnormal);
-    with ``fail_value`` given, the failing nodes (gpslc_last_info) get that value instead and the others keep
-    their scores — what a batch of independent MH proposals needs."""
+def _marshal_nodes(nodes, ctx):
+    """gpslc_node array for a sequence of (F, LS, scale, noise, target); arrays shared by several nodes of the call (the
+    same feature block under several parameter values, one target) are converted and addressed once."""
     cnt = len(nodes)
     arr = (_lib.Node * max(cnt, 1))()
     keep = []
-    memo = {}          # nodes of one call share arrays (the same feature block under several parameter values, one target)
+    memo = {}
 
     def conv(a, shape=None):
         key = id(a)
@@ -546,12 +541,37 @@ def nodesLogpdf(nodes, ctx: Context, fail_value=None):
         nd.scale = float(scale)
         nd.noise = float(noise)
         nd.target = tgp
+    return arr, (keep, memo)
+
+
+def nodesLogpdf(nodes, ctx: Context, fail_value=None):
+    """The fused whole-model score (gpslc_nodes_logpdf): ``nodes`` is a sequence of (F, LS, scale, noise, target)
+    — F (n, nF) or None, LS (nF,), scalars, target (n,) — one per Gen address to re-score (:X => k => :X, :T /
+    :logitT, :Y with F = [U | X | T]; src/model_likelihood.jl:13-120).  One call, and for n <= 640 one kernel
+    launch, whatever the nodes' feature counts.  Returns the log-densities (len(nodes),).
+    A covariance that is not positive definite raises PosDefException (PDMats' behaviour inside Gen's mvnormal);
+    with ``fail_value`` given, the failing nodes (gpslc_last_info) get that value instead and the others keep
+    their scores — what a batch of independent MH proposals needs."""
+    cnt = len(nodes)
+    arr, _keep = _marshal_nodes(nodes, ctx)
     out = np.empty(cnt)
     st = ctx.lib.gpslc_nodes_logpdf(ctx.h, cnt, C.cast(arr, C.c_void_p), _p(out))
     if st > 0 and fail_value is not None:
         out[ctx.last_info(cnt) != 0] = fail_value
         return out
     ctx.check(st)
+    return out
+
+
+def nodesDraw(nodes, ctx: Context):
+    """Draws from the nodes' Gaussian priors (gpslc_nodes_draw): ``nodes`` as for nodesLogpdf, with standard normals z
+    in the target slot; returns chol(K) z per node as the columns of an (n, len(nodes)) array — the `mvnormal(zeros(n),
+    cov)` of an elliptical slice's auxiliary vector (src/inference.jl:225-232) or of a prior draw, with the
+    random numbers still drawn on the host.  n <= 640 (GPSLCError -1007 beyond)."""
+    cnt = len(nodes)
+    arr, _keep = _marshal_nodes(nodes, ctx)
+    out = np.empty((ctx.n, cnt), order="F")
+    ctx.check(ctx.lib.gpslc_nodes_draw(ctx.h, cnt, C.cast(arr, C.c_void_p), _p(out), None))
     return out
 
 

@@ -833,7 +833,8 @@ bool fast_path_ok(const gpslc_ctx* c, int nF_max, int64_t count) {
 
 // scores `count` nodes in ONE launch; logdet/quad/info per node come back through the pinned buffer.
 // Returns the first failing pivot (0 = all fine); logpdf[i] = -(n log 2pi + logdet_i + quad_i) / 2.
-int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* logpdf) {
+// draw_out (optional, host, n x count): node i also returns chol(K_i) * target_i.
+int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* logpdf, double* draw_out = nullptr) {
     ensure_streams(c);
     const size_t n = (size_t)c->n;
     size_t doubles = 0;
@@ -845,7 +846,8 @@ int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* l
     const size_t off_out = ((size_t)count * sizeof(SmallNode) + 63) & ~size_t(63);
     // 4 results + 8 stamp words per node (+ 8 x 8 per-wave words of node 0 for the mid-size kernel: measurement build)
     const size_t off_data = off_out + ((size_t)count * 12 + 64) * sizeof(double);
-    pin_reserve(c, off_data + doubles * sizeof(double));
+    const size_t off_draw = off_data + doubles * sizeof(double);          // [count][n] draws (pinned, written by the kernel)
+    pin_reserve(c, off_draw + (draw_out ? (size_t)count * n * sizeof(double) : 0));
     void* dbase = nullptr;
     HC(hipHostGetDevicePointer(&dbase, c->pin, 0));
     char* dev = static_cast<char*>(dbase);
@@ -879,6 +881,7 @@ int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* l
     a.n = (int)n; a.NB = (int)((n + 15) / 16);
     a.out = reinterpret_cast<double*>(dev + off_out);
     a.stamps = nullptr;
+    a.draw = draw_out ? reinterpret_cast<double*>(dev + off_draw) : nullptr;
     const bool in_lds = small_gp_lds_bytes((int)n, nF_max) <= kLdsBytes;
     if (!in_lds) {       // mid-size kernel: per-node scratch for the finished block columns and the scaled features
         const size_t per = (mid_gp_scratch_doubles((int)n, nF_max) + 31) & ~size_t(31);
@@ -913,6 +916,7 @@ int small_nodes_logpdf(gpslc_ctx* c, int count, const HostNode* nodes, double* l
                         sp[8 * w], sp[8 * w + 1], sp[8 * w + 2], sp[8 * w + 3], sp[8 * w + 4], sp[8 * w + 5]);
     }
 #endif
+    if (draw_out) memcpy(draw_out, c->pin + off_draw, (size_t)count * n * sizeof(double));
     const double l2pi = 1.8378770664093454835606594728112;
     int first = 0;
     c->last_info.resize((size_t)count);
@@ -1364,6 +1368,39 @@ int gpslc_nodes_logpdf(gpslc_ctx* c, int32_t count, const gpslc_node* nodes, dou
         }
         c->last_info = infos;
         return first;
+    });
+}
+
+int gpslc_nodes_draw(gpslc_ctx* c, int32_t count, const gpslc_node* nodes, double* draws, double* logpdf_or_null) {
+    if (!c) return -1;
+    if (count < 0) return bad_arg(c, 2, "count < 0");
+    if (count > 0 && !nodes) return bad_arg(c, 3, "nodes is NULL");
+    if (count > 0 && !draws) return bad_arg(c, 4, "draws is NULL");
+    int nF_max = 0;
+    for (int i = 0; i < count; ++i) {
+        const gpslc_node& q = nodes[i];
+        if (q.nF < 0 || q.nF > 32 || (q.nF > 0 && (!q.F || !q.ls)) || !q.target)
+            return bad_arg(c, 3, "node with nF outside 0..32 or a NULL feature / lengthscale / target pointer");
+        nF_max = std::max(nF_max, (int)q.nF);
+    }
+    if (count == 0) { c->last_info.clear(); return GPSLC_OK; }
+    if (!fast_path_ok(c, nF_max, count)) {
+        c->err = "gpslc_nodes_draw: only the single-workgroup node kernels keep the whole factor (n <= 640, fp64 kernel, count <= 512)";
+        return GPSLC_ERR_UNSUPPORTED;
+    }
+    return guarded(c, [&]() {
+        std::vector<HostNode> hn((size_t)count);
+        for (int i = 0; i < count; ++i) {
+            HostNode& h = hn[i];
+            h = HostNode{};
+            h.nF = nodes[i].nF;
+            h.F[0] = nodes[i].F; h.nFpart[0] = nodes[i].nF; h.ls[0] = nodes[i].ls;
+            h.scale = nodes[i].scale; h.noise = nodes[i].noise; h.target = nodes[i].target;
+        }
+        std::vector<double> lp((size_t)count);
+        const int st = small_nodes_logpdf(c, count, hn.data(), lp.data(), draws);
+        if (logpdf_or_null) memcpy(logpdf_or_null, lp.data(), (size_t)count * sizeof(double));
+        return st;
     });
 }
 

@@ -251,6 +251,8 @@ struct SmallArgs {
     double* stamps;         // measurement build only: [count][8] phase timings, else null
     double* scratch;        // mid-size kernel: per-node device scratch (finished block columns + scaled features)
     long long scratch_stride;
+    double* draw;           // non-null: [count][n], node i also returns chol(K_i) * target_i (target = standard normals):
+                            //   a draw from N(0, K_i) — the auxiliary vector of an elliptical slice, a prior draw
 };
 size_t small_gp_lds_bytes(int n, int nF);
 void launch_small_gp(const SmallArgs& a, int count, int nF_max, hipStream_t st);

@@ -150,7 +150,18 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
             double lcc;
             sm_factor_rows_lds(r, li, lane, SB * p, bad, lcc, bcl + wave * SB);
             if (is_diag) {
-                if (wave == 0) ldv[SB * p + li] = lcc;   // the factor's diagonal block itself is never read again
+                if (wave == 0) {
+                    ldv[SB * p + li] = lcc;              // the score never reads the factor's diagonal block again
+                    if (a.draw) {
+                        // a draw does.  The other carrying waves may still be loading their copy of the block's rows, of
+                        // which only the lower triangle matters: L_pp goes, transposed, into the strictly UPPER triangle
+                        // (element (c, li) <- L[li][c], c < li); its diagonal is ldv.
+                        double* up = SBLK(p, p) + li * SB;
+#pragma unroll
+                        for (int c = 0; c < SB; ++c)
+                            if (c < li) up[c] = r[c];
+                    }
+                }
             } else if (dst) {
 #pragma unroll
                 for (int c = 0; c < SB; ++c) dst[c * SB] = r[c];
@@ -226,6 +237,22 @@ __global__ __launch_bounds__(SM_THREADS) void small_gp_logpdf_kernel(SmallArgs a
         if (a.stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_fac += t - tq; tq = t; }
     }
 
+    if (a.draw) {          // draw = L * target: row i of the factor from the LDS blocks, target from the (pinned) input
+        for (int i = tid; i < NP; i += SM_THREADS) yv[i] = (i < n) ? nd.target[i] : 0.0;
+        __syncthreads();
+        for (int i = tid; i < n; i += SM_THREADS) {
+            const int bi = i >> 4, ri = i & 15;
+            double acc = 0.0;
+            for (int bk = 0; bk < bi; ++bk) {
+                const double* B = SBLK(bi, bk);
+                for (int j = 0; j < SB; ++j) acc = fma(B[j * SB + ri], yv[SB * bk + j], acc);
+            }
+            const double* D = SBLK(bi, bi) + ri * SB;            // row ri of L_pp, kept transposed above the diagonal
+            for (int j = 0; j < ri; ++j) acc = fma(D[j], yv[SB * bi + j], acc);
+            acc = fma(ldv[i], yv[i], acc);
+            a.draw[(long long)blockIdx.x * n + i] = acc;
+        }
+    }
     if (wave == 0) {
         double q = 0.0, ld = 0.0;
         for (int i = lane; i < n; i += 64) {
@@ -290,6 +317,7 @@ struct MidCtx {
     const double* tgt;      // right-hand side [NP]
     int n, NB, NP, wave, lane, tid;
     int own;                // block rows of column q owned by this wave: i = q + own + 8u (own = 7 - wave)
+    int draw;               // the factor's diagonal blocks are kept too (SmallArgs::draw)
 #ifdef GPSLC_DIAG
     long long* tt;          // per-wave phase clocks (measurement build)
 #endif
@@ -428,7 +456,14 @@ __device__ __forceinline__ void mid_factor(const MidCtx& c, int p, int& bad) {
             double lcc;
             sm_factor_rows_lds(r, li, lane, SB * p, bad, lcc, c.bc);
             if (is_diag) {
-                if (wave == 0 && q0 == 0) c.ldv[SB * p + li] = lcc;
+                if (wave == 0 && q0 == 0) {
+                    c.ldv[SB * p + li] = lcc;
+                    if (c.draw) {                        // L_pp: lower triangle, exact diagonal, zeros above
+                        double* dd = MBLK(p, p) + li;
+#pragma unroll
+                        for (int cc = 0; cc < SB; ++cc) dd[cc * SB] = (li > cc) ? r[cc] : (li == cc ? lcc : 0.0);
+                    }
+                }
             } else if (src) {
                 double* dst = MBLK(p + 1 + (q >> 4), p) + (q & 15);
 #pragma unroll
@@ -530,7 +565,7 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
         for (int i = tid; i < NP; i += SM_THREADS) dstt[i] = (i < n) ? nd.target[i] : 0.0;
     }
     MidCtx mc;
-    mc.X = X; mc.Cp = C0; mc.Cn = C0; mc.ldv = ldv; mc.Xrow = xrow; mc.tid = tid; mc.bc = bcl + wave * SB; mc.fl = fl; mc.featg = featg; mc.tgt = (FL ? fl : featg) + (long long)nd.nF * NP;
+    mc.X = X; mc.Cp = C0; mc.Cn = C0; mc.ldv = ldv; mc.Xrow = xrow; mc.tid = tid; mc.bc = bcl + wave * SB; mc.draw = a.draw != nullptr; mc.fl = fl; mc.featg = featg; mc.tgt = (FL ? fl : featg) + (long long)nd.nF * NP;
     mc.n = n; mc.NB = NB; mc.NP = NP; mc.wave = wave; mc.lane = lane; mc.own = SM_WAVES - 1 - wave;
 #ifdef GPSLC_DIAG
     long long tt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -570,6 +605,18 @@ __global__ __launch_bounds__(SM_THREADS) void mid_gp_logpdf_kernel(SmallArgs a) 
         for (int j = 0; j < 6; ++j) a.stamps[8 * (long long)gridDim.x + 8 * wave + j] = (double)tt[j];
 #endif
 
+    if (a.draw) {          // draw = L * target: row i of the factor from the scratch (L2), target from its staged copy
+        for (int i = tid; i < n; i += SM_THREADS) {
+            const int bi = i >> 4, ri = i & 15;
+            double acc = 0.0;
+            for (int bk = 0; bk <= bi; ++bk) {
+                const double* B = MBLK(bi, bk);
+                const int jmax = bk == bi ? ri : SB - 1;
+                for (int j = 0; j <= jmax; ++j) acc = fma(B[j * SB + ri], mc.tgt[SB * bk + j], acc);
+            }
+            a.draw[(long long)blockIdx.x * n + i] = acc;
+        }
+    }
     if (wave == 0) {      // z = row 0 of the right-hand side blocks (NB, k): z[16k + c] = X(NB, k)[c*16 + 0]
         double q = 0.0, ld = 0.0;
         for (int i = lane; i < n; i += 64) {

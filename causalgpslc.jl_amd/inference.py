@@ -187,7 +187,7 @@ class _RealTChain:
         self.v = v
         self.U = [math.sqrt(v["uNoise"]) * (self.Lsig @ rng.standard_normal(self.n)) for _ in range(nU)]
         if binary:                        # :logitT from its prior, the :T => i => :T nodes are constrained
-            self.logitT = np.linalg.cholesky(self._t_cov()) @ rng.standard_normal(self.n)
+            self.logitT = self._t_draw(rng.standard_normal(self.n))
         self.s_u = self.score_u()
         self.s_x, self.s_t, self.s_y = self.score_xty()     # s_x: array over k (empty without covariates)
         self.s_b = self.score_b() if binary else 0.0
@@ -216,6 +216,15 @@ class _RealTChain:
         d2 = np.maximum(sq[:, None] + sq[None, :] - 2.0 * (Fs @ Fs.T), 0.0)
         return self.v["tScale"] * np.exp(-d2) + self.v["tNoise"] * np.eye(self.n)
 
+    def _t_draw(self, z):
+        """chol(logitTCov) z — Gen's `mvnormal(zeros(n), logitTCov)` (src/model_likelihood.jl:25-33; the slice's auxiliary
+        vector, src/inference.jl:225-232) with the host's normals: on the GPU, in the launch that factors the node's
+        covariance (gpslc_nodes_draw), while the node kernels cover n; beyond (n > 640) on the host."""
+        F, ls = self._t_features()
+        if F.shape[1] and self.n <= 640:
+            return api.nodesDraw([(F, ls, self.v["tScale"], self.v["tNoise"], z)], self.ctx)[:, 0]
+        return np.linalg.cholesky(self._t_cov()) @ z
+
     def score_b(self, logitT=None):
         """sum_i log bernoulli(T_i; expit(logitT_i)) (generateBinaryT, src/model_prior.jl:21-24) — host scalar work."""
         l = self.logitT if logitT is None else logitT
@@ -223,7 +232,7 @@ class _RealTChain:
 
     def elliptical_slice_logitT(self):
         """`elliptical_slice(trace, :logitT, zeros(n), logitTCov)` (src/inference.jl:232)."""
-        nu = np.linalg.cholesky(self._t_cov()) @ self.rng.standard_normal(self.n)
+        nu = self._t_draw(self.rng.standard_normal(self.n))
         log_y = self.s_b + math.log(self.rng.random())
         theta = self.rng.uniform(0.0, 2.0 * math.pi)
         lo, hi = theta - 2.0 * math.pi, theta

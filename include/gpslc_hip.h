@@ -46,6 +46,7 @@ typedef struct gpslc_ctx gpslc_ctx;
 #define GPSLC_ERR_INTERNAL   (-1004)
 #define GPSLC_ERR_IO         (-1005)  /* posterior pack: file cannot be opened / read / written   */
 #define GPSLC_ERR_FORMAT     (-1006)  /* posterior pack: bad magic, truncated or trailing bytes   */
+#define GPSLC_ERR_UNSUPPORTED (-1007) /* the entry point does not cover this problem size / mode  */
 
 /* flags for gpslc_create */
 #define GPSLC_FLAG_DEFAULT            0u
@@ -133,6 +134,16 @@ typedef struct gpslc_node {
     const double* target;  /* n */
 } gpslc_node;
 int gpslc_nodes_logpdf(gpslc_ctx* ctx, int32_t count, const gpslc_node* nodes, double* logpdf /* count */);
+
+/* Draws from the nodes' priors: draws[:, i] = chol(K_i) * target_i with K_i the node's covariance as above and
+ * target_i a vector of standard normals supplied by the caller (the host keeps its random-number stream) — what Gen's
+ * `mvnormal(zeros(n), cov)` does inside `elliptical_slice(trace, addr, mu, cov)` (src/inference.jl:48-54, 92-98, 232,
+ * 348; covariances built at src/inference.jl:225-227, 286-287, 343-344) and inside `generate` for the prior draws.
+ * Same single launch as gpslc_nodes_logpdf (the factor never leaves the CU / its L2 scratch); logpdf_or_null, when
+ * given, receives log N(target_i; 0, K_i) as a by-product.  n <= 640 and count <= 512 only (GPSLC_ERR_UNSUPPORTED
+ * otherwise: the batched tiled path does not keep a whole factor per node).  Return value / gpslc_last_info as above. */
+int gpslc_nodes_draw(gpslc_ctx* ctx, int32_t count, const gpslc_node* nodes, double* draws /* n x count */,
+                     double* logpdf_or_null /* count */);
 
 /* log N(x_s; 0, covscale_s * cov) for S vectors and one dense n x n covariance: the :U => u => :U nodes
  * (generateUfromSigmaU, src/model_likelihood.jl:4-10 with uCov = SigmaU * uNoise; generateU,

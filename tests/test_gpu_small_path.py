@@ -138,3 +138,36 @@ def test_random_sizes_and_feature_counts(gp, seed):
     assert np.allclose(out, ref, rtol=1e-10, atol=1e-9), (n, out, ref)
     again = gp.nodesLogpdf(nodes, ctx)
     assert np.array_equal(out, again)          # deterministic: no race in the LDS / scratch hand-overs
+
+
+@pytest.mark.parametrize("n", [1, 5, 16, 17, 100, 150, 176, 177, 272, 400, 640])
+def test_prior_draws_are_the_cholesky_factor_times_the_normals(gp, n):
+    """gpslc_nodes_draw: chol(K) z for heterogeneous nodes in one launch — Gen's mvnormal(zeros(n), cov) with the
+    host's normals (the auxiliary vector of elliptical_slice, src/inference.jl:225-232) — against numpy's Cholesky of the
+    oracle's covariance, across the LDS-resident and the left-looking kernel."""
+    rng = np.random.default_rng(4000 + n)
+    ctx = gp.Context(n, 0, 0)
+    nodes, refs = [], []
+    for nF in (1, 3, 8, 16):
+        F = rng.standard_normal((n, nF))
+        ls = rng.uniform(0.6, 2.0, nF)
+        scale, noise = rng.uniform(0.5, 2.0), rng.uniform(0.3, 1.5)
+        z = rng.standard_normal(n)
+        nodes.append((F, ls, scale, noise, z))
+        K = orc.process_cov(orc.rbf_kernel_log(F, F, ls), scale, noise)
+        refs.append(np.linalg.cholesky(K) @ z)
+    out = gp.nodesDraw(nodes, ctx)
+    assert out.shape == (n, len(nodes))
+    for i, ref in enumerate(refs):
+        assert np.allclose(out[:, i], ref, rtol=1e-10, atol=1e-11 * np.abs(ref).max()), (n, i, np.abs(out[:, i] - ref).max())
+    # the scores of the same call are unaffected by the draw mode
+    lp = gp.nodesLogpdf(nodes, ctx)
+    assert np.allclose(lp, [_ref(*q) for q in nodes], rtol=1e-11)
+
+
+def test_prior_draws_beyond_the_single_workgroup_kernels_are_refused(gp):
+    n = 700
+    rng = np.random.default_rng(1)
+    with pytest.raises(gp.GPSLCError) as ei:
+        gp.nodesDraw([(rng.standard_normal((n, 2)), np.ones(2), 1.0, 0.5, rng.standard_normal(n))], gp.Context(n, 0, 0))
+    assert ei.value.status == -1007
