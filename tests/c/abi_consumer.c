@@ -49,6 +49,21 @@ int main(void) {
             const double ref = closed_form(n, nodes[s].scale, nodes[s].noise, x);
             if (!(fabs(out2[s] - ref) <= 1e-10 * fabs(ref))) { printf("node %d: %.12g vs %.12g\n", s, out2[s], ref); ++bad; }
         }
+        /* (b') a prior draw: chol(K) e_0 is the first column of the factor, K[:,0] / sqrt(K[0,0]) */
+        if (n <= 640) {
+            double* z = (double*)calloc((size_t)n, sizeof(double));
+            double* w = (double*)malloc(sizeof(double) * n);
+            z[0] = 1.0;
+            gpslc_node dn = {0, 0, NULL, NULL, 1.1, 0.9, z};
+            st = gpslc_nodes_draw(ctx, 1, &dn, w, NULL);
+            if (st != GPSLC_OK) { printf("gpslc_nodes_draw: status %d (%s)\n", st, gpslc_last_error(ctx)); return 5; }
+            const double d0 = sqrt(1.1 + 0.9);
+            for (int i = 0; i < n; ++i) {
+                const double ref = (i == 0 ? 2.0 : 1.1) / d0;
+                if (!(fabs(w[i] - ref) <= 1e-12)) { printf("draw row %d: %.15g vs %.15g\n", i, w[i], ref); ++bad; break; }
+            }
+            free(z); free(w);
+        }
         /* (c) argument errors come back as negative status codes, never as a crash */
         if (gpslc_gp_logpdf(ctx, 1, 0, NULL, 1, NULL, scale, noise, NULL, 1, out) != -9) ++bad;
         /* (d) a matrix that is not positive definite -> LAPACK-style info (scale * 11' with negative noise) */
