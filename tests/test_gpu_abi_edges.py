@@ -159,3 +159,27 @@ def test_plain_c_consumer(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
     assert "gfx950" in r.stdout and r.stdout.strip().endswith("ok")
+
+
+def test_nodes_draw_edges(gp):
+    """gpslc_nodes_draw argument / failure behaviour: count = 0 is a no-op, NULL output is argument #4, a covariance that
+    is not positive definite comes back as LAPACK-style info (never a crash), and the optional log-density by-product is
+    the score gpslc_nodes_logpdf gives."""
+    from causalgpslc_jl_amd import _lib, api
+    n = 150
+    ctx = gp.Context(n, 0, 0)
+    lib = ctx.lib
+    assert lib.gpslc_nodes_draw(ctx.h, 0, None, None, None) == 0
+    rng = np.random.default_rng(3)
+    F, ls, z = rng.standard_normal((n, 3)), np.array([1.0, 1.5, 0.8]), rng.standard_normal(n)
+    arr, keep = api._marshal_nodes([(F, ls, 1.2, 0.5, z)], ctx)
+    assert lib.gpslc_nodes_draw(ctx.h, 1, C.cast(arr, C.c_void_p), None, None) == -4
+    out, lp = np.empty((n, 1), order="F"), np.empty(1)
+    assert lib.gpslc_nodes_draw(ctx.h, 1, C.cast(arr, C.c_void_p), out.ctypes.data_as(C.c_void_p), lp.ctypes.data_as(C.c_void_p)) == 0
+    assert abs(lp[0] - gp.nodesLogpdf([(F, ls, 1.2, 0.5, z)], ctx)[0]) <= 1e-12 * abs(lp[0])
+    K = orc.process_cov(orc.rbf_kernel_log(F, F, ls), 1.2, 0.5)
+    assert np.allclose(out[:, 0], np.linalg.cholesky(K) @ z, rtol=1e-10, atol=1e-12)
+    # negative noise: scale * exp(...) - 2 I is indefinite -> positive info, PosDefException through the mirror
+    with pytest.raises(gp.PosDefException):
+        gp.nodesDraw([(F, ls, 1.2, -2.0, z)], ctx)
+    assert ctx.last_info(1)[0] > 0
