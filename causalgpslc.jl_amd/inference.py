@@ -291,6 +291,13 @@ class _RealTChain:
             c = self._cur_cache = {"key": self.U, "Um": Um, "Ft": Ft, "Fy": Fy}
         return c
 
+    def _xcol(self, k):
+        """Covariate k as ONE array object for the whole chain (the nodes of a call that share it are marshalled once)."""
+        c = getattr(self, "_xcols", None)
+        if c is None:
+            c = self._xcols = [np.ascontiguousarray(self.X[:, j], dtype=np.float64) for j in range(self.nX)]
+        return c[k]
+
     def _uxls_model(self, v):
         """`toMatrix(uxLS, nX, nU)` of src/model_prior.jl:110 -> (nX, nU); row k feeds X node k."""
         return toMatrixModel([v["uxLS"][u] for u in range(self.nU)], self.nX, self.nU)
@@ -329,7 +336,7 @@ class _RealTChain:
         if nx:
             ls = self._uxls_model(v)
             for k in range(self.nX):
-                nodes.append((Um, ls[k], v["xScale"][k], v["xNoise"][k], self.X[:, k]))
+                nodes.append((Um, ls[k], v["xScale"][k], v["xNoise"][k], self._xcol(k)))
         Ft, lst = self._t_features(U, v)
         target = self.logitT if self.binary else self.T
         has_t = Ft.shape[1] > 0
@@ -458,7 +465,7 @@ class _RealTChain:
         v2 = pr["v2"]
         if pr["node"] == "x":
             k = pr["xk"]
-            return (self._umodel(), self._uxls_model(v2)[k], v2["xScale"][k], v2["xNoise"][k], self.X[:, k])
+            return (self._umodel(), self._uxls_model(v2)[k], v2["xScale"][k], v2["xNoise"][k], self._xcol(k))
         if pr["node"] == "t":
             F, ls = self._t_features(None, v2)
             return (F, ls, v2["tScale"], v2["tNoise"], self.logitT if self.binary else self.T)
