@@ -445,8 +445,8 @@ def predictCounterfactualEffects(g: GPSLCObject, nSamplesPerMixture, fidelity=10
 
 def summarizeEstimates(samples, credible_interval=0.90):
     """summarizeEstimates(samples; credible_interval=0.90) (src/driver.jl:129-149): Individual, Mean,
-    LowerBound, UpperBound per row of the n x m sample matrix, computed on the GPU (in-LDS sort per individual,
-    Julia's type-7 quantile).  Rows longer than 16384 samples are not supported yet."""
+    LowerBound, UpperBound per row of the n x m sample matrix, computed on the GPU (Julia's type-7 quantile: in-LDS
+    sort per individual up to 16384 samples per row, exact radix select beyond)."""
     s = _f(np.atleast_2d(samples))
     n, m = s.shape
     mean, lo, hi = np.empty(n), np.empty(n), np.empty(n)

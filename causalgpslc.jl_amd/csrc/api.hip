@@ -1607,8 +1607,8 @@ int gpslc_likelihood_distribution(gpslc_ctx* c, const double* U, const double* u
 static int summarize_impl(gpslc_ctx* c, const double* dx, int64_t n, int64_t m, int64_t rs, int64_t cs,
                           double ci, double* dmean, double* dlo, double* dhi) {
     ensure_streams(c);
-    int mpad = 1;
-    while (mpad < m) mpad <<= 1;
+    int mpad = 1;                                     // LDS image of a row (sorted in place): rows up to 16384 samples
+    while (mpad < m && mpad < 16384) mpad <<= 1;      // (longer rows: radix select, no image)
     const double lowerQ = (1.0 - ci) / 2.0;          // src/driver.jl:130-131
     const double upperQ = 1.0 - lowerQ;
     launch_summarize(SummArgs{dx, rs, cs, (int)n, (int)m, mpad, lowerQ, upperQ, dmean, dlo, dhi}, c->streams[0]);
@@ -1622,7 +1622,7 @@ int gpslc_summarize_dev(gpslc_ctx* c, const double* samples, int64_t n, int64_t 
     if (!c) return -1;
     if (!samples) return bad_arg(c, 2, "samples is NULL");
     if (n < 1) return bad_arg(c, 3, "n < 1");
-    if (m < 1 || m > 16384) return bad_arg(c, 4, "m must be in 1..16384 (one LDS-resident row per workgroup)");
+    if (m < 1 || m > 2147483647LL) return bad_arg(c, 4, "m must be in 1..2^31-1");
     if (!(credible_interval > 0.0 && credible_interval < 1.0)) return bad_arg(c, 7, "credible_interval not in (0,1)");
     if (!mean || !lower || !upper) return bad_arg(c, 8, "output is NULL");
     return guarded(c, [&]() { return summarize_impl(c, samples, n, m, row_stride, col_stride, credible_interval,
@@ -1634,7 +1634,7 @@ int gpslc_summarize(gpslc_ctx* c, const double* samples, int64_t n, int64_t m, d
     if (!c) return -1;
     if (!samples) return bad_arg(c, 2, "samples is NULL");
     if (n < 1) return bad_arg(c, 3, "n < 1");
-    if (m < 1 || m > 16384) return bad_arg(c, 4, "m must be in 1..16384 (one LDS-resident row per workgroup)");
+    if (m < 1 || m > 2147483647LL) return bad_arg(c, 4, "m must be in 1..2^31-1");
     if (!(credible_interval > 0.0 && credible_interval < 1.0)) return bad_arg(c, 5, "credible_interval not in (0,1)");
     if (!mean || !lower || !upper) return bad_arg(c, 6, "output is NULL");
     return guarded(c, [&]() {

@@ -869,7 +869,119 @@ __global__ __launch_bounds__(256) void summarize_kernel(SummArgs a) {
         a.upper[i] = julia_quantile_sorted(v, a.m, a.upperQ);
     }
 }
+// Rows longer than one LDS image (m > 16384: S * spp of a BASELINE-size posterior): exact order statistics by radix
+// select on order-preserving 64-bit keys instead of a sort.  One workgroup = 16 consecutive individuals (for the
+// column-major n x m sample matrix a wave then reads whole 128-byte lines: 16 rows x 4 samples), thread (r, jj) walks
+// samples jj, jj + 16, ... of row r.  Eight passes of 8-bit digits from the top; both quantiles' selections run in the
+// same pass (two histograms per row in LDS, ds_add_u32); a ninth pass finds the successor of each selected element
+// (count of keys <= it, minimum key above it).  Julia's type-7 interpolation as in julia_quantile_sorted.
+#define SUMM_RW 16
+__device__ __forceinline__ unsigned long long summ_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double summ_unkey(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+__global__ __launch_bounds__(256) void summarize_select_kernel(SummArgs a) {
+    __shared__ unsigned int hist[SUMM_RW][2][256];
+    __shared__ unsigned long long prefix[SUMM_RW][2], mingt[SUMM_RW][2];
+    __shared__ unsigned int rank[SUMM_RW][2], cntle[SUMM_RW][2];
+    __shared__ double rsum[4][SUMM_RW];
+    const int tid = threadIdx.x, r = tid & (SUMM_RW - 1), jj = tid >> 4;
+    const long long i = (long long)blockIdx.x * SUMM_RW + r;
+    const bool live = i < a.n;
+    const double* row = a.x + (live ? i : 0) * a.rs;
+    const int m = a.m;
+    // ranks (0-based) of the lower neighbour of each quantile: j - 1 with j = clamp(trunc(m p + 1 - p), 1, m - 1)
+    int jq[2];
+    double gq[2];
+    {
+#pragma clang fp contract(off)
+        const double ps[2] = {a.lowerQ, a.upperQ};
+        for (int q = 0; q < 2; ++q) {
+            const double aleph = (double)m * ps[q] + (1.0 - ps[q]);
+            int j = (int)aleph;
+            j = min(max(j, 1), m - 1);
+            jq[q] = j;
+            gq[q] = fmin(fmax(aleph - (double)j, 0.0), 1.0);
+        }
+    }
+    for (int t = tid; t < SUMM_RW * 2 * 256; t += 256) (&hist[0][0][0])[t] = 0u;
+    if (tid < SUMM_RW * 2) {
+        const int rr = tid & (SUMM_RW - 1), q = tid >> 4;
+        prefix[rr][q] = 0ull; rank[rr][q] = (unsigned)(jq[q] - 1); cntle[rr][q] = 0u; mingt[rr][q] = ~0ull;
+    }
+    // mean: per-thread strided partial, then the 4 samples-lanes of a wave, then the 4 waves
+    double acc = 0.0;
+    if (live)
+        for (int j = jj; j < m; j += 16) acc += row[(long long)j * a.cs];
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if ((tid & 63) < SUMM_RW) rsum[tid >> 6][r] = acc;
+    __syncthreads();
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        if (live) {
+            const unsigned long long p0 = prefix[r][0], p1 = prefix[r][1];
+            for (int j = jj; j < m; j += 16) {
+                const unsigned long long k = summ_key(row[(long long)j * a.cs]);
+                const unsigned long long hi = pass == 0 ? 0ull : (k >> (shift + 8));
+                const unsigned d = (unsigned)(k >> shift) & 255u;
+                if (hi == p0) atomicAdd(&hist[r][0][d], 1u);
+                if (hi == p1) atomicAdd(&hist[r][1][d], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < SUMM_RW * 2) {
+            const int rr = tid & (SUMM_RW - 1), q = tid >> 4;
+            unsigned cum = 0, want = rank[rr][q], d = 0;
+            for (; d < 255u; ++d) {
+                const unsigned cnt = hist[rr][q][d];
+                if (want < cum + cnt) break;
+                cum += cnt;
+            }
+            prefix[rr][q] = (prefix[rr][q] << 8) | d;
+            rank[rr][q] = want - cum;
+        }
+        __syncthreads();
+        for (int t = tid; t < SUMM_RW * 2 * 256; t += 256) (&hist[0][0][0])[t] = 0u;
+        __syncthreads();
+    }
+    // successor of each selected element
+    if (live) {
+        const unsigned long long k0 = prefix[r][0], k1 = prefix[r][1];
+        unsigned c0 = 0, c1 = 0;
+        unsigned long long g0 = ~0ull, g1 = ~0ull;
+        for (int j = jj; j < m; j += 16) {
+            const unsigned long long k = summ_key(row[(long long)j * a.cs]);
+            if (k <= k0) ++c0; else g0 = k < g0 ? k : g0;
+            if (k <= k1) ++c1; else g1 = k < g1 ? k : g1;
+        }
+        atomicAdd(&cntle[r][0], c0); atomicAdd(&cntle[r][1], c1);
+        atomicMin(&mingt[r][0], g0); atomicMin(&mingt[r][1], g1);
+    }
+    __syncthreads();
+    if (tid < SUMM_RW && i < a.n) {
+#pragma clang fp contract(off)
+        double qv[2];
+        for (int q = 0; q < 2; ++q) {
+            const double av = summ_unkey(prefix[r][q]);                  // sorted[j - 1]
+            const double bv = cntle[r][q] > (unsigned)jq[q] ? av : summ_unkey(mingt[r][q]);   // sorted[j]
+            qv[q] = m == 1 ? av : av + gq[q] * (bv - av);
+        }
+        a.mean[i] = ((rsum[0][r] + rsum[1][r]) + (rsum[2][r] + rsum[3][r])) / (double)m;
+        a.lower[i] = qv[0];
+        a.upper[i] = qv[1];
+    }
+}
+
 void launch_summarize(const SummArgs& a, hipStream_t st) {
+    if (a.m > 16384) {
+        hipLaunchKernelGGL(summarize_select_kernel, dim3((a.n + SUMM_RW - 1) / SUMM_RW), dim3(256), 0, st, a);
+        return;
+    }
     static DeviceOnce attr_set;
     lds_opt_in(attr_set, (const void*)summarize_kernel, 16384 * 8);
     hipLaunchKernelGGL(summarize_kernel, dim3(a.n), dim3(256), (size_t)a.mpad * 8, st, a);

@@ -212,7 +212,8 @@ int gpslc_sate_samples(const double* meanSATE, const double* varSATE, int64_t S,
 
 /* summarizeEstimates(samples; credible_interval) (src/driver.jl:129-149): per-individual Mean and the
  * (1-ci)/2 and 1-(1-ci)/2 quantiles (Julia's Statistics.quantile, type 7) of an n x m sample matrix
- * (column-major, samples[i + n*j]); m <= 16384.  The _dev variant reads device memory with explicit strides
+ * (column-major, samples[i + n*j]); rows of up to 16384 samples are sorted in LDS, longer ones (S * spp of a large
+ * posterior) go through an exact radix select.  The _dev variant reads device memory with explicit strides
  * (sample (i, j) at samples[i*row_stride + j*col_stride]) so that level l of gpslc_predict_dev's ite_draws
  * (L x n x M, level fastest) is summarised in place with samples = draws + l, row_stride = L,
  * col_stride = L*n, and writes device outputs: the draw tensor never leaves HBM. */

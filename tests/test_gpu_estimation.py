@@ -399,8 +399,19 @@ def test_summarize_estimates_on_device(gp):
         assert np.array_equal(out["LowerBound"], lo) and np.array_equal(out["UpperBound"], hi), (n, m)
         assert np.allclose(out["Mean"], mean, rtol=1e-14, atol=1e-16)
         assert np.array_equal(out["Individual"], np.arange(1, n + 1))
-    with pytest.raises(gp.GPSLCError):
-        gp.summarizeEstimates(np.zeros((2, 20000)))
+    # rows longer than one LDS image (S * spp of a BASELINE-size posterior: 5000 x 10): exact radix select, 16
+    # individuals per workgroup — ragged row counts, heavy ties, negative values, the level-strided _dev layout's sizes
+    for (n, m) in [(1, 16385), (17, 20000), (40, 50000), (5, 131072)]:
+        x = rng.standard_normal((n, m)) * rng.uniform(0.1, 10, (n, 1)) + rng.uniform(-3, 3, (n, 1))
+        if n >= 17:
+            x[3] = np.round(x[3])                      # many duplicates around the quantiles
+            x[5] = -np.abs(x[5])
+            x[7, :] = 2.5                              # a constant row
+        for ci in (0.9, 0.5):
+            out = gp.summarizeEstimates(x, credible_interval=ci)
+            mean, lo, hi = orc.summarize_estimates(x, ci)
+            assert np.array_equal(out["LowerBound"], lo) and np.array_equal(out["UpperBound"], hi), (n, m, ci)
+            assert np.allclose(out["Mean"], mean, rtol=1e-13, atol=1e-15)
 
 
 def test_multi_level_mfma_mean_ite_path(gp):
