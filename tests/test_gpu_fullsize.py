@@ -227,3 +227,21 @@ def test_config4_shape_n4096_64_levels(gp):
     # SATE-only call (no back-substitution / MeanITE pass) gives the same numbers
     ms2, vs2, _ = gp.predict(g, doTs)
     assert np.array_equal(ms2, ms) and np.array_equal(vs2, vs)
+
+
+def test_sample_ite_then_summarize_with_more_draws_than_an_lds_row(gp):
+    """The reference's end-user workflow at a posterior size its defaults never reach (src/driver.jl:86-89, 129-149):
+    sampleITE over S = 1800 posterior samples x 10 draws = 18,000 draws per individual (> 16,384: the radix-select
+    summary), N = 512.  The summary of the GPU's draws equals NumPy's type-7 quantiles of the same matrix bit for bit,
+    and the draws' mean over everything tracks the mean of the MeanSATEs."""
+    n, D, K, S, spp = 512, 4, 1, 1800, 10
+    g, (X, T, Y, post) = _obj(gp, n, D, K, S, seed=77)
+    doT = 0.35
+    ite = gp.sampleITE(g, doT, samplesPerPosterior=spp, seed=5)
+    assert ite.shape == (n, S * spp) and np.all(np.isfinite(ite))
+    out = gp.summarizeEstimates(ite, credible_interval=0.9)
+    mean, lo, hi = orc.summarize_estimates(ite, 0.9)
+    assert np.array_equal(out["LowerBound"], lo) and np.array_equal(out["UpperBound"], hi)
+    assert np.allclose(out["Mean"], mean, rtol=1e-12, atol=1e-14)
+    ms, vs = gp.SATEDistributions(g, doT)
+    assert abs(ite.mean() - ms.mean()) <= 0.05 * abs(ms.mean()) + 5.0 * np.sqrt(np.mean(vs) / (n * S * spp)) + 1e-3
