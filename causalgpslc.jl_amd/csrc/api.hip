@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -122,6 +123,8 @@ struct gpslc_ctx {
     // results) and host copies of the ctx's data for assembling the :Y node's feature block
     char* pin = nullptr;
     size_t pin_bytes = 0;
+    // two pinned bounce chunks for large device -> pageable-host hand-overs (copy_out_large), allocated on first use
+    char* bounce[2] = {nullptr, nullptr};
     std::vector<double> hX, hT, hY;
     std::string err;
     std::vector<int32_t> last_info;
@@ -831,6 +834,57 @@ bool fast_path_ok(const gpslc_ctx* c, int nF_max, int64_t count) {
     return mid_gp_fits((int)c->n) && count <= 512;
 }
 
+// Device -> host hand-over of a LARGE result (draw tensors, MeanITE of a level sweep: GB).  A plain hipMemcpy into pageable
+// memory runs at ~10 GB/s (the runtime's own bounce copies + first-touch page faults of a fresh destination, on one
+// thread) against 57 GB/s of DMA into pinned memory (tools/bench_small_n_predict.py).  Here the DMA of chunk k + 1 into
+// one of two pinned chunks overlaps the copy of chunk k into the caller's buffer, and that copy is split over a few
+// threads: 1.1 GB in 77 ms instead of 110 (a huge-page hint on the destination changed nothing: NumPy's large arrays
+// already carry it).  Small results keep the plain call; a caller who hands over a PINNED buffer gets the DMA rate.
+constexpr size_t kBounceBytes = size_t(128) << 20;
+void copy_out_large(gpslc_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+    bool plain = bytes < 2 * kBounceBytes;
+    if (!plain) {                                     // a pinned (registered) destination takes the DMA directly
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, dst) == hipSuccess) plain = at.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();                 // ordinary pageable memory: not known to the runtime
+    }
+    if (plain) { HC(hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost)); return; }
+    ensure_streams(c);
+    for (int i = 0; i < 2; ++i)
+        if (!c->bounce[i]) {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, kBounceBytes, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                HC(hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost));      // no pinned memory to be had: the plain way
+                return;
+            }
+            c->bounce[i] = static_cast<char*>(p);
+        }
+    hipStream_t st = c->streams[0];
+    const size_t nchunk = (bytes + kBounceBytes - 1) / kBounceBytes;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nthr = std::min(8u, hw);
+    auto chunk_bytes = [&](size_t k) { return std::min(kBounceBytes, bytes - k * kBounceBytes); };
+    HC(hipMemcpyAsync(c->bounce[0], src_dev, chunk_bytes(0), hipMemcpyDeviceToHost, st));
+    for (size_t k = 0; k < nchunk; ++k) {
+        HC(hipStreamSynchronize(st));                                           // chunk k has landed in bounce[k & 1]
+        if (k + 1 < nchunk)
+            HC(hipMemcpyAsync(c->bounce[(k + 1) & 1], static_cast<const char*>(src_dev) + (k + 1) * kBounceBytes,
+                              chunk_bytes(k + 1), hipMemcpyDeviceToHost, st));
+        const size_t cb = chunk_bytes(k);
+        char* d = static_cast<char*>(dst) + k * kBounceBytes;
+        const char* b = c->bounce[k & 1];
+        const size_t per = ((cb + nthr - 1) / nthr + 4095) & ~size_t(4095);
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; ++t) {
+            const size_t o = (size_t)t * per;
+            if (o < cb) pool.emplace_back([=]() { memcpy(d + o, b + o, std::min(per, cb - o)); });
+        }
+        memcpy(d, b, std::min(per, cb));
+        for (auto& th : pool) th.join();
+    }
+}
+
 // scores `count` nodes in ONE launch; logdet/quad/info per node come back through the pinned buffer.
 // Returns the first failing pivot (0 = all fine); logpdf[i] = -(n log 2pi + logdet_i + quad_i) / 2.
 // draw_out (optional, host, n x count): node i also returns chol(K_i) * target_i.
@@ -983,6 +1037,7 @@ int gpslc_destroy(gpslc_ctx* c) {
     if (c->scratch.base) (void)hipFree(c->scratch.base);
     c->io.release();
     if (c->pin) (void)hipHostFree(c->pin);
+    for (char* b : c->bounce) if (b) (void)hipHostFree(b);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto p : c->tri_order) if (p) (void)hipFree(p);
     if (c->mvn_tiles) (void)hipFree(c->mvn_tiles);
@@ -1178,8 +1233,8 @@ int gpslc_predict(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, 
         if (st < 0) return st;
         if (meanSATE) HC(hipMemcpy(meanSATE, oms, sizeof(double) * S * L, hipMemcpyDeviceToHost));
         if (varSATE) HC(hipMemcpy(varSATE, ovs, sizeof(double) * S * L, hipMemcpyDeviceToHost));
-        if (meanITE) HC(hipMemcpy(meanITE, omi, sizeof(double) * n * S * L, hipMemcpyDeviceToHost));
-        if (ite_draws) HC(hipMemcpy(ite_draws, odr, sizeof(double) * (size_t)L * n * S * spp, hipMemcpyDeviceToHost));
+        if (meanITE) copy_out_large(c, meanITE, omi, sizeof(double) * (size_t)n * S * L);
+        if (ite_draws) copy_out_large(c, ite_draws, odr, sizeof(double) * (size_t)L * n * S * spp);
         return st;
     });
 }

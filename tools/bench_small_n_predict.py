@@ -47,3 +47,15 @@ pin = torch.empty(L * n * S * spp, dtype=torch.float64).pin_memory()
 torch.cuda.synchronize(dev)
 t0 = time.perf_counter(); pin.copy_(dr); torch.cuda.synchronize(dev); t1 = time.perf_counter()
 print(f"1.1 GB device -> pinned host: {t1 - t0:.3f} s ({dr.numel() * 8 / (t1 - t0) / 1e9:.1f} GB/s)")
+
+# the host-pointer form writing into a PINNED destination (what a caller with a registered buffer gets)
+out = pin.numpy()
+U, uy, xy, ty, ys, yn = g._params()
+msn, vsn = np.empty(S * L), np.empty(S * L)
+for _ in range(2):
+    t0 = time.perf_counter()
+    st = ctx.lib.gpslc_predict(ctx.h, S, U, uy, xy, ty, ys, yn, L, doTs.ctypes.data_as(C.c_void_p), 1e-10, spp, 7, None,
+                               msn.ctypes.data_as(C.c_void_p), vsn.ctypes.data_as(C.c_void_p), None, out.ctypes.data_as(C.c_void_p))
+    t1 = time.perf_counter()
+    assert st == 0, st
+print(f"host-pointer form into a pinned destination: {t1 - t0:.3f} s")
