@@ -1263,7 +1263,7 @@ int gpslc_ite_distributions(gpslc_ctx* c, int64_t S, const double* U, const doub
         io.MeanITEs = om; io.CovITEs = oc; io.info = c->io.take<int>((size_t)S);
         run_predict(c, io);
         if (MeanITEs) HC(hipMemcpy(MeanITEs, om, sizeof(double) * S * n, hipMemcpyDeviceToHost));
-        if (CovITEs) HC(hipMemcpy(CovITEs, oc, sizeof(double) * S * n * n, hipMemcpyDeviceToHost));
+        if (CovITEs) copy_out_large(c, CovITEs, oc, sizeof(double) * (size_t)S * n * n);
         return first_info(c);
     });
 }
