@@ -245,3 +245,25 @@ def test_sample_ite_then_summarize_with_more_draws_than_an_lds_row(gp):
     assert np.allclose(out["Mean"], mean, rtol=1e-12, atol=1e-14)
     ms, vs = gp.SATEDistributions(g, doT)
     assert abs(ite.mean() - ms.mean()) <= 0.05 * abs(ms.mean()) + 5.0 * np.sqrt(np.mean(vs) / (n * S * spp)) + 1e-3
+
+
+def test_ite_distributions_large_hand_over_n2048(gp):
+    """ITEDistributions (src/estimation.jl:66-86) with S n^2 doubles = 268 MB of covariances: the result leaves through
+    the chunked pinned hand-over of large outputs; every sample's block must arrive intact (first / last sample against
+    the structured oracle, all of them through mean(CovITE) = VarSATE and symmetry)."""
+    n, D, K, S = 2048, 8, 2, 8
+    g, (X, T, Y, post) = _obj(gp, n, D, K, S, seed=9)
+    doT = 0.4
+    M, Cv = gp.ITEDistributions(g, doT)
+    assert M.shape == (S, n) and Cv.shape == (S, n, n)
+    ms, vs = gp.SATEDistributions(g, doT)
+    noise = g.hyperparams.predictionCovarianceNoise
+    for s in range(S):
+        assert abs(Cv[s].sum() / n ** 2 - vs[s]) <= 1e-8 * abs(vs[s]) + 1e-12
+        assert abs(M[s].mean() - ms[s]) <= 1e-9 * abs(ms[s]) + 1e-12
+        assert np.array_equal(Cv[s], Cv[s].T)
+    for s in (0, S - 1):
+        m, cov = orc.structured_ite(_sample(post, s, D, K), X, T, Y, doT)
+        cov = cov + noise * np.eye(n)
+        assert np.max(np.abs(M[s] - m)) <= 1e-8 * np.max(np.abs(m)) + 1e-13
+        assert np.max(np.abs(Cv[s] - cov)) <= 1e-8 * np.max(np.abs(cov)) + 1e-12
