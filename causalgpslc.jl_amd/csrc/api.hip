@@ -840,7 +840,7 @@ bool fast_path_ok(const gpslc_ctx* c, int nF_max, int64_t count) {
 // one of two pinned chunks overlaps the copy of chunk k into the caller's buffer, and that copy is split over a few
 // threads: 1.1 GB in 77 ms instead of 110 (a huge-page hint on the destination changed nothing: NumPy's large arrays
 // already carry it).  Small results keep the plain call; a caller who hands over a PINNED buffer gets the DMA rate.
-constexpr size_t kBounceBytes = size_t(128) << 20;
+constexpr size_t kBounceBytes = size_t(64) << 20;
 void copy_out_large(gpslc_ctx* c, void* dst, const void* src_dev, size_t bytes) {
     bool plain = bytes < 2 * kBounceBytes;
     if (!plain) {                                     // a pinned (registered) destination takes the DMA directly
@@ -1130,7 +1130,7 @@ int gpslc_rbf_log(gpslc_ctx* c, const double* X1, const double* X2, int64_t n, i
         launch_rbf_log(dA, dB, n, d, dl, ls_len, o, c->streams[0]);
         HC(hipGetLastError());
         HC(hipStreamSynchronize(c->streams[0]));
-        HC(hipMemcpy(out, o, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+        copy_out_large(c, out, o, sizeof(double) * (size_t)n * n);
         return GPSLC_OK;
     });
 }
@@ -1162,7 +1162,7 @@ int gpslc_process_cov(gpslc_ctx* c, const double* logcov, int64_t n, double scal
         launch_process_cov(dA, n, scale, noise, o, c->streams[0]);
         HC(hipGetLastError());
         HC(hipStreamSynchronize(c->streams[0]));
-        HC(hipMemcpy(out, o, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+        copy_out_large(c, out, o, sizeof(double) * (size_t)n * n);
         return GPSLC_OK;
     });
 }
@@ -1609,7 +1609,7 @@ int gpslc_likelihood_distribution(gpslc_ctx* c, const double* U, const double* u
             if (!host) return;
             launch_rect_gather(RectGatherArgs{R, n, nt, outb.as<double>(), diag_add}, st);
             HC(hipStreamSynchronize(st));
-            HC(hipMemcpy(host, outb.p, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+            copy_out_large(c, host, outb.p, (size_t)n * n * 8);
         };
         emit(Kt, CovWW, 0.0);
         emit(Kst, CovWWs, 0.0);
