@@ -878,7 +878,10 @@ void copy_out_large(gpslc_ctx* c, void* dst, const void* src_dev, size_t bytes) 
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < nthr; ++t) {
             const size_t o = (size_t)t * per;
-            if (o < cb) pool.emplace_back([=]() { memcpy(d + o, b + o, std::min(per, cb - o)); });
+            if (o >= cb) break;
+            const size_t len = std::min(per, cb - o);
+            try { pool.emplace_back([=]() { memcpy(d + o, b + o, len); }); }
+            catch (...) { memcpy(d + o, b + o, len); }        // no thread to be had: copy this slice here
         }
         memcpy(d, b, std::min(per, cb));
         for (auto& th : pool) th.join();
