@@ -268,7 +268,10 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st, int prof_base = 0) {
     static bool dbg_done = false;
     DevBuf dbg_buf;
     size_t dbg_words = 0;
-    if (dbg_m > 0 && !dbg_done && g.shape == 0 && g.mi == dbg_m) {
+    // GPSLC_GEMM_DBG_FUSEK=<K>: the first FUSED in-panel launch whose K loop is K tiles deep instead
+    static const int dbg_fk = diag_env("GPSLC_GEMM_DBG_FUSEK", -1);
+    const bool dbg_fused = dbg_fk >= 0 && g.fuse && g.accumulate && (g.k1 - g.k0) == dbg_fk;
+    if (!dbg_done && ((dbg_fk < 0 && dbg_m > 0 && g.shape == 0 && g.mi == dbg_m) || dbg_fused)) {
         dbg_words = (size_t)g.ntiles * g.nbatch * 8;
         dbg_buf.alloc(dbg_words * 8);
         HC(hipMemset(dbg_buf.p, 0, dbg_words * 8));
