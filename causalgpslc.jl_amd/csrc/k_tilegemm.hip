@@ -295,8 +295,15 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
             const double* __restrict__ Wl = tref_tile(g.F, b, 0, g.fk) + (lg * GP_TS + li);   // W(c, c') at c'*128 + c
             double* lP = smem;                                   // [wr][nc][m][v][64 lanes], 64 KiB
             if (nslab == 0 || no_update) __syncthreads();        // (the K loop ends with a barrier otherwise)
+            // The fragments of W = inv(L_kk) come from L2 (the tile is shared by every item of the launch).  Loaded right
+            // before their four MFMAs, every group waited a full L2 round trip (in-kernel stamps: 95 k clocks of second
+            // phase per item against 37 k of MFMA time): they run WD groups (WD x 256 MFMA clocks) ahead instead.
+            constexpr int WD = 4;
             if (wc == 0) {
-                // X(:, 0:64) * W(64:128, 0:64)^T for the right-hand waves
+                // X(:, 0:64) * W(64:128, 0:64)^T for the right-hand waves; group q = 16 nc + 4 n + v
+                double wn[WD];
+#pragma unroll
+                for (int q = 0; q < WD; ++q) wn[q] = Wl[(16 * ((q >> 2) & 3) + 4 * (q & 3)) * GP_TS + 64 + 16 * (q >> 4)];
 #pragma unroll
                 for (int nc = 0; nc < 4; ++nc) {
                     d4 st[4];
@@ -306,7 +313,9 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                     for (int n = 0; n < 4; ++n)
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            const double w = Wl[(16 * n + 4 * v) * GP_TS + 64 + 16 * nc];
+                            const int q = 16 * nc + 4 * n + v, q1 = q + WD;
+                            const double w = wn[q % WD];
+                            if (q1 < 64) wn[q % WD] = Wl[(16 * ((q1 >> 2) & 3) + 4 * (q1 & 3)) * GP_TS + 64 + 16 * (q1 >> 4)];
 #pragma unroll
                             for (int m = 0; m < 4; ++m) st[m] = mfma_step<0>(w, acc[m][n][v], st[m]);
                         }
@@ -319,6 +328,13 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
             __syncthreads();
             double* __restrict__ Co = Ct + ((wc * 64 + lg) * GP_TS + wr * 64 + li);
             const double* __restrict__ Wq = Wl + (64 * wc) * GP_TS + 64 * wc;     // the wave's diagonal quadrant of W
+            double wq[WD];
+#pragma unroll
+            for (int t = 0; t < WD; ++t) {
+                int c1 = 0, r1 = t >> 2;
+                while (r1 > c1) { r1 -= c1 + 1; ++c1; }
+                wq[t] = Wq[(16 * r1 + 4 * (t & 3)) * GP_TS + 16 * c1];
+            }
 #pragma unroll
             for (int nc = 0; nc < 4; ++nc) {
                 d4 st[4];
@@ -335,7 +351,13 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                     if (n <= nc) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            const double w = Wq[(16 * n + 4 * v) * GP_TS + 16 * nc];
+                            const int t = 4 * (nc * (nc + 1) / 2 + n) + v, t1 = t + WD;     // 40 live groups in the order of use
+                            const double w = wq[t % WD];
+                            if (t1 < 40) {
+                                int c1 = 0, r1 = t1 >> 2;
+                                while (r1 > c1) { r1 -= c1 + 1; ++c1; }
+                                wq[t % WD] = Wq[(16 * r1 + 4 * (t1 & 3)) * GP_TS + 16 * c1];
+                            }
 #pragma unroll
                             for (int m = 0; m < 4; ++m) st[m] = mfma_step<0>(w, acc[m][n][v], st[m]);
                         }
