@@ -592,9 +592,31 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         ga.X = io.X; ga.T = c->dT; ga.p = io.p; ga.s0 = s0;
         ga.n = n; ga.nX = io.nX; ga.nU = io.nU; ga.nt = nt; ga.M = M; ga.part = part;
         ga.with_sums = with_sums ? 1 : 0;
+#ifdef GPSLC_DIAG
+        static const int gram_dbg = diag_env("GPSLC_GRAM_DBG", 0);
+        static bool gram_dbg_done = false;
+        DevBuf gdbg;
+        if (gram_dbg && !gram_dbg_done) {
+            const size_t words = (size_t)4 * nb * (nt * (nt + 1) / 2);
+            gdbg.alloc(words * 8);
+            HC(hipMemset(gdbg.p, 0, words * 8));
+            ga.dbg = gdbg.as<unsigned long long>();
+        }
+#endif
         ga.f32 = (c->flags & GPSLC_FLAG_FP32_KERNEL) ? 1 : 0;
         ga.binary_t = (c->binary_t && io.nU == c->nU && io.nX == c->nX && io.Y == c->dY) ? 1 : 0;   // ctx data only
         launch_gram(ga, nb, st);
+#ifdef GPSLC_DIAG
+        if (ga.dbg) {      // GPSLC_GRAM_DBG: dump the first launch's per-workgroup stamps
+            HC(hipStreamSynchronize(st));
+            const size_t words = (size_t)4 * nb * (nt * (nt + 1) / 2);
+            std::vector<unsigned long long> h(words);
+            HC(hipMemcpy(h.data(), ga.dbg, words * 8, hipMemcpyDeviceToHost));
+            FILE* f = fopen("gpurun_out/gram_dbg.bin", "wb");
+            if (f) { fwrite(h.data(), 8, words, f); fclose(f); }
+            gram_dbg_done = true;
+        }
+#endif
 
         RhsArgs ra{};
         ra.T = c->dT; ra.Y = io.Y; ra.y_sstride = io.y_sstride; ra.tyLS = io.p.tyLS; ra.doT = io.doT; ra.s0 = s0;

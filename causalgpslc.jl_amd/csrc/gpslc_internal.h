@@ -127,6 +127,7 @@ struct GramArgs {
     int with_sums;
     int f32;           // evaluate the RBF kernel in fp32 (GPSLC_FLAG_FP32_KERNEL)
     int binary_t;      // every T is 0 or 1: e_ij is 1 or exp(-1/tyLS^2), no per-pair exp (bit-identical)
+    unsigned long long* dbg;   // measurement build only: per-workgroup s_memtime stamps [entry, staged, columns done, end], or null
 };
 
 // launchers (implemented in the k_*.hip files); all asynchronous on `st`

@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const long long s = g.s0 + b;
+#ifdef GPSLC_DIAG
+    const unsigned long long dt0 = g.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#endif
     int ti, tj;
     {
         const int t = blockIdx.x;
@@ -53,21 +56,54 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     const int gi0 = ti * GP_TS, gj0 = tj * GP_TS;
 
     // stage features scaled by 1/LS (zeros on the padding): (x - x')^2 / LS^2 = (x/LS - x'/LS)^2
-    for (int idx = tid; idx < F * GP_TS; idx += 256) {
-        const int f = idx >> 7, r = idx & 127;
-        const double* src;
-        double l;
-        if (f < g.nU) { src = g.p.U + s * g.p.u_sstride + (long long)f * n; l = g.p.uyLS[s * g.nU + f]; }
-        else { src = g.X + (long long)(f - g.nU) * n; l = g.p.xyLS[s * g.nX + (f - g.nU)]; }
-        const double il = 1.0 / l;
-        fr[f * GP_TS + r] = (RT)((gi0 + r < n) ? src[gi0 + r] * il : 0.0);
-        fc[f * GP_TS + r] = (RT)((gj0 + r < n) ? src[gj0 + r] * il : 0.0);
+    if (FT > 0) {
+        // exact feature count: ALL loads of the staging (lengthscale, row value, column value per (feature, instance)
+        // pair of this thread) are issued before the first is used — branch-free, clamped addresses.  As a loop with
+        // guarded loads every iteration waited for its own round trips: in-kernel stamps showed 17.7 k clocks of staging
+        // per workgroup, a quarter of its life.
+        constexpr int NIT = (FT * GP_TS + 255) / 256;
+        double lv[NIT > 0 ? NIT : 1], av[NIT > 0 ? NIT : 1], cv[NIT > 0 ? NIT : 1];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + 256 * k;
+            const int f = min(idx >> 7, FT - 1), r = idx & 127;
+            const bool isu = f < g.nU;
+            const double* src = isu ? g.p.U + s * g.p.u_sstride + (long long)f * n : g.X + (long long)(f - g.nU) * n;
+            const double* lp = isu ? g.p.uyLS + s * g.nU + f : g.p.xyLS + s * g.nX + (f - g.nU);
+            lv[k] = *lp;
+            av[k] = src[min(gi0 + r, n - 1)];
+            cv[k] = src[min(gj0 + r, n - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx < FT * GP_TS) {
+                const int f = idx >> 7, r = idx & 127;
+                const double il = 1.0 / lv[k];
+                fr[f * GP_TS + r] = (RT)((gi0 + r < n) ? av[k] * il : 0.0);
+                fc[f * GP_TS + r] = (RT)((gj0 + r < n) ? cv[k] * il : 0.0);
+            }
+        }
+    } else {
+        for (int idx = tid; idx < F * GP_TS; idx += 256) {
+            const int f = idx >> 7, r = idx & 127;
+            const double* src;
+            double l;
+            if (f < g.nU) { src = g.p.U + s * g.p.u_sstride + (long long)f * n; l = g.p.uyLS[s * g.nU + f]; }
+            else { src = g.X + (long long)(f - g.nU) * n; l = g.p.xyLS[s * g.nX + (f - g.nU)]; }
+            const double il = 1.0 / l;
+            fr[f * GP_TS + r] = (RT)((gi0 + r < n) ? src[gi0 + r] * il : 0.0);
+            fc[f * GP_TS + r] = (RT)((gj0 + r < n) ? src[gj0 + r] * il : 0.0);
+        }
     }
     if (tid < GP_TS) {
         tr[tid] = (RT)((gi0 + tid < n) ? g.T[gi0 + tid] : 0.0);
         tc[tid] = (RT)((gj0 + tid < n) ? g.T[gj0 + tid] : 0.0);
     }
     __syncthreads();
+#ifdef GPSLC_DIAG
+    const unsigned long long dt1 = g.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#endif
 
     const double ys = g.p.yScale[s];
     const double yn = g.p.yNoise[s];
@@ -130,7 +166,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
                     // diagonal: + yNoise inside, identity on the padding
                     Av = (gi == gj) ? (inside ? Kv + yn : 1.0) : Kv;
                 }
-                tile[cq * GP_TS + rp] = Av;
+                __builtin_nontemporal_store(Av, &tile[cq * GP_TS + rp]);
                 rsB[p] += Bv; rsK[p] += Kv;
                 csB += Bv; csK += Kv;
             }
@@ -147,6 +183,12 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     };
     if (ti != tj && gi0 + GP_TS <= n && gj0 + GP_TS <= n) columns(std::true_type{});
     else columns(std::false_type{});
+#ifdef GPSLC_DIAG
+    if (g.dbg && tid == 0) {
+        unsigned long long* d = g.dbg + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        d[0] = dt0; d[1] = dt1; d[2] = __builtin_amdgcn_s_memtime(); d[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     // diagonal tile: the full square was computed, column sums are complete
     if (!g.with_sums || ti == tj) return;
 
