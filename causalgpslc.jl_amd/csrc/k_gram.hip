@@ -184,9 +184,13 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     if (ti != tj && gi0 + GP_TS <= n && gj0 + GP_TS <= n) columns(std::true_type{});
     else columns(std::false_type{});
 #ifdef GPSLC_DIAG
-    if (g.dbg && tid == 0) {
-        unsigned long long* d = g.dbg + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
-        d[0] = dt0; d[1] = dt1; d[2] = __builtin_amdgcn_s_memtime(); d[3] = __builtin_amdgcn_s_memrealtime();
+    if (g.dbg) {     // [entry, staged, columns done, tile stores drained]
+        const unsigned long long dt2 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            unsigned long long* d = g.dbg + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            d[0] = dt0; d[1] = dt1; d[2] = dt2; d[3] = __builtin_amdgcn_s_memtime();
+        }
     }
 #endif
     // diagonal tile: the full square was computed, column sums are complete
