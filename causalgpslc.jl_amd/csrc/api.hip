@@ -597,7 +597,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         static bool gram_dbg_done = false;
         DevBuf gdbg;
         if (gram_dbg && !gram_dbg_done) {
-            const size_t words = (size_t)4 * nb * (nt * (nt + 1) / 2);
+            const size_t words = (size_t)8 * nb * (nt * (nt + 1) / 2);
             gdbg.alloc(words * 8);
             HC(hipMemset(gdbg.p, 0, words * 8));
             ga.dbg = gdbg.as<unsigned long long>();
@@ -609,7 +609,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
 #ifdef GPSLC_DIAG
         if (ga.dbg) {      // GPSLC_GRAM_DBG: dump the first launch's per-workgroup stamps
             HC(hipStreamSynchronize(st));
-            const size_t words = (size_t)4 * nb * (nt * (nt + 1) / 2);
+            const size_t words = (size_t)8 * nb * (nt * (nt + 1) / 2);
             std::vector<unsigned long long> h(words);
             HC(hipMemcpy(h.data(), ga.dbg, words * 8, hipMemcpyDeviceToHost));
             FILE* f = fopen("gpurun_out/gram_dbg.bin", "wb");

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     const long long s = g.s0 + b;
 #ifdef GPSLC_DIAG
     const unsigned long long dt0 = g.dbg ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long dr0 = g.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
 #endif
     int ti, tj;
     {
@@ -188,8 +189,9 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
         const unsigned long long dt2 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) {
-            unsigned long long* d = g.dbg + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            unsigned long long* d = g.dbg + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
             d[0] = dt0; d[1] = dt1; d[2] = dt2; d[3] = __builtin_amdgcn_s_memtime();
+            d[4] = dr0; d[5] = __builtin_amdgcn_s_memrealtime();
         }
     }
 #endif

@@ -211,13 +211,34 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                 // c' > c.  Slab s carries c' in [16 (s&7), 16 (s&7) + 16), so only the output column
                 // sub-tiles n with 64 wc + 16 n + 15 >= 16 (s&7) contribute: 44 % fewer MFMAs.
                 const int nlo = ACC ? 0 : min(4, max(0, (s & 7) - 4 * wc));
+                // trailing updates (no second phase, registers to spare): the fragments of k-step ks + 1 are read from LDS
+                // before the 16 MFMAs of k-step ks are issued, so that a wave never starts a k-step with an LDS round trip
+                constexpr bool PIPE = ACC && !FUSE && DIAG == 0;
+                double afn[4], bfn[4];
+                if (PIPE) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) afn[m] = pa[16 * m];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bfn[n] = pb[16 * n];
+                }
 #pragma unroll
                 for (int ks = 0; ks < KS / 4; ++ks) {
                     double af[4], bf[4];
+                    if (PIPE) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) af[m] = pa[ks * 4 * LROW + 16 * m];
+                        for (int m = 0; m < 4; ++m) { af[m] = afn[m]; bf[m] = bfn[m]; }
+                        if (ks + 1 < KS / 4) {
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) bf[n] = pb[ks * 4 * LROW + 16 * n];
+                            for (int m = 0; m < 4; ++m) afn[m] = pa[(ks + 1) * 4 * LROW + 16 * m];
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) bfn[n] = pb[(ks + 1) * 4 * LROW + 16 * n];
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) af[m] = pa[ks * 4 * LROW + 16 * m];
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) bf[n] = pb[ks * 4 * LROW + 16 * n];
+                    }
                     if (mlive == 4 && nlo == 0) {
 #pragma unroll
                         for (int m = 0; m < 4; ++m)

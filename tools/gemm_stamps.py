@@ -29,3 +29,12 @@ print(f"gap between consecutive items of a workgroup: mean {gaps.mean():.0f}, me
       f"workgroups busy {busy / span:.3f} of their span; items per workgroup {len(d) / len(np.unique(blk)):.1f}")
 rt = d[:, 6].astype(np.int64)
 print(f"launch span {(rt.max() - rt.min()) / 100.0:.0f} us (realtime counter)")
+# shader clock: s_memtime ticks between the ends of consecutive items of a workgroup against the 100 MHz realtime counter
+ghz = []
+for b in np.unique(blk):
+    m = blk == b
+    o = np.argsort(st[m][:, 3])
+    e, r = st[m][o, 3], rt[m][o]
+    if len(e) > 1 and r[-1] > r[0]:
+        ghz.append((e[-1] - e[0]) / ((r[-1] - r[0]) * 10.0))
+print(f"s_memtime runs at {np.median(ghz):.3f} GHz against s_memrealtime during this launch (median over workgroups)")
