@@ -45,6 +45,9 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBPS = 8000.0
+# pure fp64 VALU issue time per posterior sample at N=4096 D=8 nU=2, 2.4 GHz (DESIGN.md §4 "Ceilings")
+GRAM_VALU_US_N4096 = 18.6
+ITE_MEAN_VALU_US_N4096 = 31.4
 KERNEL_SRC = os.path.join(ROOT, "causalgpslc.jl_amd", "csrc", "k_tilegemm.hip")
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_tile_gemm.json")
 
@@ -70,11 +73,20 @@ def parse():
     ap.add_argument("--unit-b-levels", type=int, default=16, help="intervention levels per posterior sample (they share one factor of A)")
     ap.add_argument("--unit-b-spp", type=int, default=10, help="draws per (sample, level): the reference's default")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[3] leg (64 intervention levels per sample)")
+    ap.add_argument("--config4-levels", type=int, default=64)
+    ap.add_argument("--config4-steps", type=int, default=2)
+    ap.add_argument("--no-configs", action="store_true", help="skip the short timed runs of BASELINE configs[1] and configs[4]")
     ap.add_argument("--binary-t", action="store_true", help="Bernoulli(0.5) treatments (BASELINE config 5 shape)")
     ap.add_argument("--fp32-kernel", action="store_true", help="mixed precision: RBF evaluation in fp32 (config 5)")
     ap.add_argument("--diag-lib", action="store_true",
                     help="measurement only: load libgpslc_hip_diag.so (make diag), the build in which the GPSLC_* "
                          "environment switches exist; never used for reported numbers")
+    ap.add_argument("--lib", default="", help="measurement only: load this build of the library instead (kernel A/B variants, "
+                                              "`make variant`); the JSON line is labelled as a measurement")
+    ap.add_argument("--timing-only", action="store_true",
+                    help="measurement only (timing-only kernel variants whose results are garbage by construction): ignore "
+                         "the status of the calls and skip every result check; the line is labelled")
     return ap.parse_args()
 
 
@@ -83,11 +95,46 @@ def git_blob_sha(path):
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
+def pmc_traffic(default_config):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of the default command, or None with the
+    reason: the summary records the git blob hash of the kernel source it was taken from, and a different source today
+    means the number no longer describes this kernel."""
+    if not default_config or not os.path.exists(PMC_SUMMARY):
+        return None, "no PMC summary for this configuration"
+    pm = json.load(open(PMC_SUMMARY))
+    if pm.get("kernel_src_sha") != git_blob_sha(KERNEL_SRC):
+        return None, f"STALE: k_tilegemm.hip changed since {os.path.relpath(PMC_SUMMARY, ROOT)} was taken; withheld"
+    return pm.get("hbm_bytes_per_launch"), ("bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), "
+                                             f"{os.path.relpath(PMC_SUMMARY, ROOT)}; kernel source hash matches")
+
+
+def count_gpus_sysfs():
+    """GPUs of this box from the KFD topology (nodes with SIMDs), without loading torch or any HIP runtime in the
+    launcher process; None when the topology is not readable."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(base)
+    except OSError:
+        return None
+    n = 0
+    for d in nodes:
+        try:
+            props = dict(l.split()[:2] for l in open(os.path.join(base, d, "properties")) if len(l.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n
+
+
 def self_launch(a):
     """--gpus N > 1 outside a process group: start the N ranks as a child job and pass its exit code on.
-    Nothing in this process has touched the GPU (torch.cuda.device_count() does not initialise it)."""
-    import torch
-    have = torch.cuda.device_count()
+    This launcher never touches the GPU: the device count comes from sysfs (torch's device_count() as the fallback
+    only — it does not initialise the GPU on this image)."""
+    have = count_gpus_sysfs()
+    if have is None:
+        import torch
+        have = torch.cuda.device_count()
     if have < a.gpus:
         print(f"bench.py: --gpus {a.gpus} requested but this box has {have} GPU(s); refusing to run a "
               f"{have}-GPU job under an {a.gpus}-GPU label", file=sys.stderr, flush=True)
@@ -126,10 +173,13 @@ def cpu_baseline(n, D, K, units, X, T, Y, post, doT):
                                    float(post["tyLS"][s]), float(post["yNoise"][s]), float(post["yScale"][s]),
                                    post["U"][:, :, s] if K else None)
     ref = []
+    unit0 = None
     t0 = time.perf_counter()
     for s in range(units):
         M, Cv = orc.ite_distributions([sample(s)], X, T, Y, doT)
         ref.append(orc.conditional_sate(M[0], Cv[0]))
+        if s == 0:
+            unit0 = (np.array(M[0]), np.array(Cv[0]))     # literal MeanITE and CovITE + jitter of (sample 0, doT)
     dt = time.perf_counter() - t0
     # the same units with the structured algorithm the GPU path uses (one Cholesky, augmented right-hand sides):
     # what a CPU gains from the algorithm alone — reported beside the literal restatement, not instead of it
@@ -145,10 +195,45 @@ def cpu_baseline(n, D, K, units, X, T, Y, post, doT):
            "structured_value": units / dts,
            "structured_note": "same units with the structured algorithm of the GPU path (one Cholesky + augmented "
                               "right-hand sides, SATE mean/variance) in NumPy/SciPy on the same cores"}
-    return rec, ref
+    return rec, ref, unit0
 
 
-def measure_units(gp, synth, np, torch, a, dev, local_rank, X, T, Y, obj, dX, dT, dY):
+def structured_unit0(n, D, K, X, T, Y, post, doT, pred_noise=1e-10):
+    """(MeanITE, CovITE + jitter) of (sample 0, doT) from the structured restatement: the parity reference of unit B
+    when the literal leg did not run (--no-cpu-baseline)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gpslc_oracle as orc
+    import numpy as np
+    p = orc.PosteriorSample(post["uyLS"][:, 0] if K else None, post["xyLS"][:, 0] if D else None,
+                            float(post["tyLS"][0]), float(post["yNoise"][0]), float(post["yScale"][0]),
+                            post["U"][:, :, 0] if K else None)
+    m, cov = orc.structured_ite(p, X, T, Y, doT)
+    return np.array(m), (cov + cov.T) / 2 + pred_noise * np.eye(n)
+
+
+def unit_b_parity(np, M0, C0, mi_gpu, draw_gpu, z, ref_name):
+    """One (sample, level) unit of the full-covariance path at the size the line quotes unit B on: MeanITE and one
+    predictive draw with the caller's normals against chol(CovITE + jitter) of the CPU restatement
+    (src/estimation.jl:95-109).  Bound on the draw: SURVEY §8d's 1e-8 ||L_c|| ||z|| where the conditioning permits it,
+    i.e. max(1e-8, 1e-15 cond(CovITE + jitter)) — a Cholesky factor moves by cond x the 1e-15 relative rounding of
+    forming CovITE (tests/test_gpu_estimation.py uses the same rule)."""
+    ev = np.linalg.eigvalsh(C0)
+    lam_max, lam_min = float(ev[-1]), float(ev[0])
+    Lc = np.linalg.cholesky(C0)
+    ref = M0 + Lc @ z
+    cond = lam_max / max(lam_min, 1e-300)
+    bound = max(1e-8, 1e-15 * cond) * np.sqrt(lam_max) * float(np.linalg.norm(z)) + 1e-9 * float(np.linalg.norm(ref))
+    err = float(np.linalg.norm(draw_gpu - ref))
+    merr = float(np.max(np.abs(mi_gpu - M0)))
+    mbound = 1e-6 * float(np.max(np.abs(M0))) + 1e-12
+    return {"draw_err": err, "draw_bound": bound, "mean_ite_err": merr, "mean_ite_bound": mbound,
+            "cond": cond, "ok": bool(err <= bound and merr <= mbound), "reference": ref_name,
+            "rule": "||draw - (M + chol(C) z)|| <= max(1e-8, 1e-15 cond(C)) sqrt(lambda_max(C)) ||z|| + 1e-9 ||ref||; "
+                    "max|MeanITE - ref| <= 1e-6 max|ref| + 1e-12; C = CovITE + 1e-10 I (src/estimation.jl:82)"}
+
+
+def measure_units(gp, synth, np, torch, a, dev, local_rank, X, T, Y, obj, dX, dT, dY, post0=None, doT0=None, unit0=None,
+                  unit0_name=""):
     """SURVEY §8d units B and C on this GPU (after the timed region; inputs resident in HBM).
 
     Unit B is defined GIVEN the factor of A ("one (sample, level) full-ITE unit given L"): the measurement sweeps
@@ -193,6 +278,19 @@ def measure_units(gp, synth, np, torch, a, dev, local_rank, X, T, Y, obj, dX, dT
         assert not info.any(), f"CovITE factorisation broke down: info = {info[info != 0][:4]}"
         return dt, prof
 
+    def parity_case():
+        """(sample 0 of the timed run, level doT0) through the full-covariance path with the caller's normals."""
+        packs = [to_dev(np.ascontiguousarray(post0[k][..., 0:1])) for k in ("U", "uyLS", "xyLS", "tyLS", "yScale", "yNoise")]
+        z = np.random.default_rng(2024).standard_normal(n)
+        dz, ddo = to_dev(z), to_dev(np.array([doT0]))
+        mI = torch.empty(n, dtype=torch.float64, device=dev)
+        dr = torch.empty(n, dtype=torch.float64, device=dev)
+        ctx.check(ctx.lib.gpslc_predict_dev(ctx.h, 1, *[ptr(t) for t in packs], 1, ptr(ddo), 1e-10, 1, 0, ptr(dz),
+                                            None, None, ptr(mI), ptr(dr)))
+        torch.cuda.synchronize()
+        assert not ctx.last_info(1).any(), "CovITE factorisation broke down in the parity unit"
+        return unit_b_parity(np, unit0[0], unit0[1], mI.cpu().numpy(), dr.cpu().numpy(), z, unit0_name)
+
     flop_b = 7.0 / 3.0 * float(n) ** 3
     Sb, Lb = a.unit_b_samples, a.unit_b_levels
     dt, (draws_l, draws_ms, draws_n) = run_case(Sb, Lb)
@@ -209,22 +307,89 @@ def measure_units(gp, synth, np, torch, a, dev, local_rank, X, T, Y, obj, dX, dT
                  "single_level": {"samples": 64, "levels": 1, "value": 64 / dt1, "ms": 1e3 * dt1,
                                   "frac": 64 * flop_b / dt1 / 1e12 / FP64_PEAK_TFLOPS,
                                   "note": "every unit pays its own unit-A work (Gram + factor of A + MeanITE) here"}}}
+    if unit0 is not None:
+        out["B"]["parity"] = parity_case()
     if draws_l > 0 and draws_ms > 0:
         sec = draws_ms * 1e-3
-        bytes_draw = 4.0 * float(n) ** 2           # one draw on its own reads the factor once (trmv)
+        bytes_unit = 4.0 * float(n) ** 2           # the lower triangle of L_c: N^2/2 doubles, streamed ONCE per unit
+        units_c = draws_n / spp
         out["C"] = {"what": "predictive draws mu + L_c z given both factors (src/estimation.jl:105 with the factor "
                             "computed once per unit): all spp draws of a unit in one pass over L_c, f64 MFMA",
                     "value": draws_n / sec, "unit": "draws/s", "launches": int(draws_l),
                     "avg_launch_ms": draws_ms / draws_l, "draws_per_unit": spp, "bound": "hbm",
-                    "algorithmic_bytes_per_draw": bytes_draw,
-                    "achieved": draws_n * bytes_draw / sec / 1e9, "peak": HBM_PEAK_GBPS, "roofline_unit": "GB/s",
-                    "frac": draws_n * bytes_draw / sec / 1e9 / HBM_PEAK_GBPS,
-                    "factor_stream_GBps": (draws_n / spp) * bytes_draw / sec / 1e9,
-                    "note": "achieved = draws x 4N^2 B / kernel time (the per-draw figure of SURVEY §8d; it exceeds "
-                            "the HBM peak as soon as the spp draws of a unit share one pass over L_c); "
-                            "factor_stream_GBps = the bytes of L_c actually streamed (once per unit) / time"}
+                    "algorithmic_bytes_per_unit": bytes_unit,
+                    "achieved": units_c * bytes_unit / sec / 1e9, "peak": HBM_PEAK_GBPS, "roofline_unit": "GB/s",
+                    "frac": units_c * bytes_unit / sec / 1e9 / HBM_PEAK_GBPS,
+                    "per_draw_equivalent_GBps": draws_n * bytes_unit / sec / 1e9,
+                    "note": "achieved = bytes of L_c actually streamed (4N^2 B once per unit, shared by its spp draws) / "
+                            "kernel time; per_draw_equivalent_GBps = SURVEY §8d's per-draw figure (4N^2 B per draw), "
+                            "which is not a traffic: it exceeds the HBM peak as soon as draws share a pass"}
     ctx.close()
     return out
+
+
+def run_config(gp, synth, np, torch, dev, local_rank, n, D, K, S, L, binary_t, fp32, steps, warmup, label):
+    """One short timed run of unit A (with MeanITE) on another BASELINE configuration, inputs resident in HBM; this
+    run's first unit is checked against the structured oracle evaluated in fp64 (SURVEY §8d tolerances)."""
+    X, T, Y, obj = synth.make_dataset(n, D, binary_t=binary_t)
+    post = synth.make_posterior(n, D, K, S, obj, seed=99)
+    doT = synth.levels(T, L) if not binary_t else np.array([1.0])[:L]
+
+    def to_dev(x):
+        return None if x is None else torch.from_numpy(np.ascontiguousarray(x.reshape(-1, order="F"))).to(dev)
+
+    def ptr(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    dX, dT, dY = to_dev(X), to_dev(T), to_dev(Y)
+    packs = [to_dev(post[k]) for k in ("U", "uyLS", "xyLS", "tyLS", "yScale", "yNoise")]
+    ddo = to_dev(doT)
+    mS = torch.empty(S * L, dtype=torch.float64, device=dev)
+    vS = torch.empty(S * L, dtype=torch.float64, device=dev)
+    mI = torch.empty(n * S * L, dtype=torch.float64, device=dev)
+    ctx = gp.Context(n, D, K, device=local_rank, profile=True, fp32_kernel=fp32)
+    ctx.check(ctx.lib.gpslc_set_data_dev(ctx.h, ptr(dX), ptr(dT), ptr(dY)))
+
+    def step():
+        ctx.check(ctx.lib.gpslc_predict_dev(ctx.h, S, *[ptr(t) for t in packs], L, ptr(ddo), 1e-10, 0, 0, None,
+                                            ptr(mS), ptr(vS), ptr(mI), None))
+    for _ in range(warmup):
+        step()
+    ctx.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = [ctx.profile_get(k) for k in (0, 1)]
+    ctx.close()
+    flop = float(n) ** 3 / 3.0 + float(n) ** 2 * (3 * (D + K + 1) + 4 + 5 * L)
+    val = S * steps / dt
+    rec = {"workload": label, "value": val, "unit": "posterior samples/s", "samples_per_step": S, "steps": steps,
+           "ms_per_step": 1e3 * dt / steps, "dtype": "f64 factorisation, f32 kernel build" if fp32 else "f64",
+           "algorithmic_flop_per_unit": flop, "ceiling_units_per_s": FP64_PEAK_TFLOPS * 1e12 / flop,
+           "frac_of_ceiling": val * flop / (FP64_PEAK_TFLOPS * 1e12)}
+    names = ("trailing_update_kernel", "fused_in_panel_kernel")
+    for nm, (ln, ms, fl) in zip(names, prof):
+        if ln > 0 and ms > 0:
+            rec[nm] = {"achieved": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                       "share_of_time": ms * 1e-3 / dt, "roofline_unit": "TFLOP/s"}
+    # parity of this run's first unit: structured oracle in fp64
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gpslc_oracle as orc
+    p0 = orc.PosteriorSample(post["uyLS"][:, 0] if K else None, post["xyLS"][:, 0] if D else None,
+                             float(post["tyLS"][0]), float(post["yNoise"][0]), float(post["yScale"][0]),
+                             post["U"][:, :, 0] if K else None)
+    rm, rv = orc.structured_sate(p0, X, T, Y, np.asarray(doT[:1], dtype=np.float64))[:2]
+    rm, rv = float(np.ravel(rm)[0]), float(np.ravel(rv)[0])
+    gm, gv = float(mS[0].item()), float(vS[0].item())
+    tol = 1e-6
+    rec["parity"] = {"mean_rel_err": abs(gm - rm) / abs(rm), "var_rel_err": abs(gv - rv) / abs(rv), "tolerance": tol,
+                     "ok": bool(abs(gm - rm) <= tol * abs(rm) + 1e-12 and
+                                abs(gv - rv) <= tol * abs(rv) + 1e-9 * float(post["yScale"][0])),
+                     "reference": "structured CPU restatement in fp64 (oracle.structured_sate), first unit of this run"}
+    return rec
 
 
 def main():
@@ -265,6 +430,8 @@ def main():
     from causalgpslc_jl_amd import synth
     if a.diag_lib:
         gp._lib.LIB_PATH = gp._lib.LIB_PATH.replace("libgpslc_hip.so", "libgpslc_hip_diag.so")
+    if a.lib:
+        gp._lib.LIB_PATH = os.path.abspath(a.lib)
 
     n, D, K, L = a.n, a.d, a.nu, a.levels
     Sr = a.samples_per_step
@@ -293,8 +460,10 @@ def main():
     gathered_v = [torch.empty_like(vS) for _ in range(world)] if use_dist else None
 
     def step():
-        ctx.check(ctx.lib.gpslc_predict_dev(ctx.h, Sr, ptr(dU), ptr(duy), ptr(dxy), ptr(dty), ptr(dys), ptr(dyn), L,
-                                            ptr(ddo), 1e-10, 0, 0, None, ptr(mS), ptr(vS), ptr(mI), None))
+        st = ctx.lib.gpslc_predict_dev(ctx.h, Sr, ptr(dU), ptr(duy), ptr(dxy), ptr(dty), ptr(dys), ptr(dyn), L,
+                                       ptr(ddo), 1e-10, 0, 0, None, ptr(mS), ptr(vS), ptr(mI), None)
+        if not a.timing_only:
+            ctx.check(st)
         if use_dist:   # the single end-of-step collective: SATE summaries of every rank's shard
             if rehearsal:   # gloo: gather through host memory
                 gm = [torch.empty(Sr * L, dtype=torch.float64) for _ in range(world)]
@@ -324,9 +493,81 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     launches, kms, kflop = ctx.profile_get(0)      # tile_gemm_nt_kernel<1, 0, 0>: the dominant kernel
-    launches1, kms1, kflop1 = ctx.profile_get(1)   # <1, 0, 1>: in-panel column update fused with the panel solve
+    launches1, kms1, kflop1 = ctx.profile_get(1)   # tile_fused_strip_kernel: in-panel column update fused with the panel solve
     kname = "tile_gemm_nt_kernel<1, 0, 0> (f64 MFMA tile update: trailing updates of the blocked Cholesky)"
-    kname1 = "tile_gemm_nt_kernel<1, 0, 1> (f64 MFMA tile update: in-panel column update fused with the panel solve)"
+    kname1 = "tile_fused_strip_kernel<8> (f64 MFMA tile update: in-panel column update fused with the panel solve)"
+
+    # ---- BASELINE configs[3]: the same posterior samples x 64 intervention levels (the sweep of
+    # src/prediction.jl:30-33 over src/estimation.jl:78-84), sharded like the L = 1 region: second timed region
+    c4 = None
+    if not a.no_config4 and not a.timing_only:
+        L4 = a.config4_levels
+        doT4 = synth.levels(T, L4)
+        ddo4 = to_dev(doT4)
+        mS4 = torch.empty(Sr * L4, dtype=torch.float64, device=dev)
+        vS4 = torch.empty(Sr * L4, dtype=torch.float64, device=dev)
+        mI4 = None if a.no_mean_ite else torch.empty(n * Sr * L4, dtype=torch.float64, device=dev)
+        g4m = [torch.empty_like(mS4) for _ in range(world)] if use_dist and not rehearsal else None
+        g4v = [torch.empty_like(vS4) for _ in range(world)] if use_dist and not rehearsal else None
+
+        def step4():
+            ctx.check(ctx.lib.gpslc_predict_dev(ctx.h, Sr, ptr(dU), ptr(duy), ptr(dxy), ptr(dty), ptr(dys), ptr(dyn), L4,
+                                                ptr(ddo4), 1e-10, 0, 0, None, ptr(mS4), ptr(vS4), ptr(mI4), None))
+            if use_dist:
+                if rehearsal:
+                    gm = [torch.empty(Sr * L4, dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(gm, mS4.cpu())
+                    dist.all_gather(gm, vS4.cpu())
+                else:
+                    dist.all_gather(g4m, mS4)
+                    dist.all_gather(g4v, vS4)
+        step4()
+        fence()
+        t4 = time.perf_counter()
+        for _ in range(a.config4_steps):
+            step4()
+        fence()
+        dt4 = time.perf_counter() - t4
+        if use_dist:
+            tt = torch.tensor([dt4], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt4 = float(tt.item())
+        c4 = {"workload": f"BASELINE configs[3] shape: N={n} D={D} nU={K}, {Sr} posterior samples per GPU per step x {L4} "
+                          f"intervention levels (unit A with MeanITE for every level; the levels of a sample share its "
+                          f"factor of A), sharded over {world} rank(s), all_gather of the (S x L) SATE arrays at step end",
+              "value": Sr * world * a.config4_steps / dt4, "unit": "posterior samples/s",
+              "sample_level_units_per_s": Sr * world * L4 * a.config4_steps / dt4, "levels": L4,
+              "steps": a.config4_steps, "warmup": 1, "ms_per_step": 1e3 * dt4 / a.config4_steps, "scaling": "weak",
+              "mean_ite": not a.no_mean_ite}
+        if rank == 0:
+            # parity of rank 0's first unit: SATE mean / variance of all levels and MeanITE of the two end levels against
+            # the structured CPU restatement
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import gpslc_oracle as orc
+            p0 = orc.PosteriorSample(post["uyLS"][:, 0] if K else None, post["xyLS"][:, 0] if D else None,
+                                     float(post["tyLS"][0]), float(post["yNoise"][0]), float(post["yScale"][0]),
+                                     post["U"][:, :, 0] if K else None)
+            rm, rv = orc.structured_sate(p0, X, T, Y, doT4)[:2]
+            gm4 = mS4.cpu().numpy().reshape(Sr, L4, order="F")[0]
+            gv4 = vS4.cpu().numpy().reshape(Sr, L4, order="F")[0]
+            tol = 1e-4 if a.fp32_kernel else 1e-6
+            okm = bool(np.all(np.abs(gm4 - rm) <= tol * np.abs(rm) + 1e-12))
+            okv = bool(np.all(np.abs(gv4 - rv) <= tol * np.abs(rv) + 1e-9 * float(post["yScale"][0])))
+            par = {"mean_rel_err": float(np.max(np.abs(gm4 - rm) / np.abs(rm))),
+                   "var_rel_err": float(np.max(np.abs(gv4 - rv) / np.abs(rv))), "levels_checked": L4, "tolerance": tol,
+                   "reference": "structured CPU restatement (oracle.structured_sate / structured_ite), rank 0's first unit"}
+            if mI4 is not None:
+                mi4 = mI4.cpu().numpy().reshape(n, Sr, L4, order="F")[:, 0, :]
+                e = 0.0
+                for l in (0, L4 - 1):
+                    m_ref = orc.structured_ite(p0, X, T, Y, float(doT4[l]))[0]
+                    e = max(e, float(np.max(np.abs(mi4[:, l] - m_ref)) / np.max(np.abs(m_ref))))
+                par["mean_ite_rel_err"] = e
+                okm = okm and e <= tol
+            par["ok"] = okm and okv
+            c4["parity"] = par
+        del mS4, vS4, mI4
+
     if kms1 > kms:
         # small N (at most one panel of tile columns): the in-panel instantiation is the dominant kernel
         launches, kms, kflop, launches1, kms1, kflop1 = launches1, kms1, kflop1, launches, kms, kflop
@@ -339,8 +580,8 @@ def main():
         # sanity: results are finite and the two SATE paths agree (mean of MeanITE == MeanSATE)
         ms_h = mS.cpu().numpy()
         vs_h = vS.cpu().numpy()
-        assert np.all(np.isfinite(ms_h)), "non-finite SATE in the benchmark output"
-        if mI is not None:
+        assert a.timing_only or np.all(np.isfinite(ms_h)), "non-finite SATE in the benchmark output"
+        if mI is not None and not a.timing_only:
             mi_h = mI.cpu().numpy().reshape(n, Sr, L, order="F")
             chk = np.max(np.abs(mi_h.mean(axis=0)[:, 0] - ms_h.reshape(Sr, L, order="F")[:, 0]))
             assert chk <= (1e-5 if a.fp32_kernel else 1e-8) * max(1.0, np.max(np.abs(ms_h))), chk
@@ -349,7 +590,7 @@ def main():
             "value": val, "unit": "posterior samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if not a.fp32_kernel else "f64 factorisation, f32 kernel build",
-            "data": "synthetic" + (" (MEASUREMENT BUILD libgpslc_hip_diag.so — not a result)" if a.diag_lib else "") + (" (REHEARSAL: all ranks on one GPU, gloo — not a result)" if rehearsal else ""),
+            "data": "synthetic" + (" (MEASUREMENT BUILD libgpslc_hip_diag.so — not a result)" if a.diag_lib else "") + (f" (MEASUREMENT BUILD {os.path.basename(a.lib)} — not a result)" if a.lib else "") + (" (TIMING ONLY: results unchecked)" if a.timing_only else "") + (" (REHEARSAL: all ranks on one GPU, gloo — not a result)" if rehearsal else ""),
             "config": {"workload": f"Synthetic N={n} D={D} nU={K}, unit A (Gram build + potrf + alpha + MeanITE + "
                                    f"SATE mean/var), L={L} level(s), {Sr} posterior samples per GPU per step"
                                    + (", binary treatment" if a.binary_t else ""),
@@ -362,15 +603,7 @@ def main():
             # rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950 correction; tools/profile_r02.sh).  The
             # summary records the git blob hash of the kernel source it was taken from: a different source today
             # means the number no longer describes this kernel, and it is withheld.
-            traffic, tnote = None, "no PMC summary for this configuration"
-            if os.path.exists(PMC_SUMMARY) and (n, D, K, L, Sr) == (4096, 8, 2, 1, 1024) and a.max_batch == 0 and a.panel == 0:
-                pm = json.load(open(PMC_SUMMARY))
-                if pm.get("kernel_src_sha") == git_blob_sha(KERNEL_SRC):
-                    traffic = pm.get("hbm_bytes_per_launch")
-                    tnote = ("bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), "
-                             "profiles/r02_pmc_tile_gemm.md; kernel source hash matches")
-                else:
-                    tnote = "STALE: k_tilegemm.hip changed since profiles/r02_pmc_tile_gemm.json was taken; withheld"
+            traffic, tnote = pmc_traffic((n, D, K, L, Sr) == (4096, 8, 2, 1, 1024) and a.max_batch == 0 and a.panel == 0)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_note": tnote,
                                "kernel": kname,
@@ -383,15 +616,14 @@ def main():
                     "achieved": kflop1 / (kms1 * 1e-3) / 1e12, "frac": kflop1 / (kms1 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                     "launches": int(launches1), "avg_launch_ms": kms1 / launches1,
                     "share_of_step_time": kms1 * 1e-3 / dt}
-        if world == 1 and not a.no_units:
-            out["units"] = measure_units(gp, synth, np, torch, a, dev, local_rank, X, T, Y, obj, dX, dT, dY)
-            out["units"]["A"] = {"what": "the headline value: one posterior sample (Gram + potrf + alpha + MeanITE + SATE)",
-                                 "value": val, "unit": "posterior samples/s",
-                                 "algorithmic_flop_per_unit": float(n) ** 3 / 3.0 + float(n) ** 2 * (3 * (D + K + 1) + 4 + 5 * L),
-                                 "ceiling_units_per_s": FP64_PEAK_TFLOPS * 1e12 /
-                                 (float(n) ** 3 / 3.0 + float(n) ** 2 * (3 * (D + K + 1) + 4 + 5 * L))}
-        if world == 1 and not a.no_cpu_baseline:
-            rec, ref = cpu_baseline(n, D, K, a.cpu_units, X, T, Y, post, float(doT[0]))
+        if c4 is not None:
+            out["config4"] = c4
+            if not c4.get("parity", {}).get("ok", True):
+                rc = 4
+        unit0, unit0_name = None, ""
+        if world == 1 and not a.no_cpu_baseline and not a.timing_only:
+            rec, ref, unit0 = cpu_baseline(n, D, K, a.cpu_units, X, T, Y, post, float(doT[0]))
+            unit0_name = "literal CPU restatement (oracle.ite_distributions: src/estimation.jl:36-50, 82), fp64"
             out["cpu_baseline"] = rec
             # the metric's second half: this run's GPU results for the very units the CPU leg computed
             ms2, vs2 = ms_h.reshape(Sr, L, order="F"), vs_h.reshape(Sr, L, order="F")
@@ -407,6 +639,44 @@ def main():
                                    "rule": "|dMean| <= tol |ref| + 1e-12 and |dVar| <= tol |ref| + 1e-9 yScale (SURVEY §8d)"}
             if not ok:
                 rc = 4
+        if world == 1 and not a.no_units and not a.timing_only:
+            ctx.close()      # the timed context's workspace (82 GB at the default batch) is not needed any more
+            if unit0 is None:
+                unit0 = structured_unit0(n, D, K, X, T, Y, post, float(doT[0]))
+                unit0_name = "structured CPU restatement (oracle.structured_ite) + 1e-10 I, fp64"
+            out["units"] = measure_units(gp, synth, np, torch, a, dev, local_rank, X, T, Y, obj, dX, dT, dY,
+                                         post0=post, doT0=float(doT[0]), unit0=unit0, unit0_name=unit0_name)
+            if not out["units"]["B"].get("parity", {}).get("ok", True):
+                rc = 4
+            flop_a = float(n) ** 3 / 3.0 + float(n) ** 2 * (3 * (D + K + 1) + 4 + 5 * L)
+            ua = {"what": "the headline value: one posterior sample (Gram + potrf + alpha + MeanITE + SATE)",
+                  "value": val, "unit": "posterior samples/s", "algorithmic_flop_per_unit": flop_a,
+                  "ceiling_units_per_s": FP64_PEAK_TFLOPS * 1e12 / flop_a,
+                  "frac_of_ceiling": val * flop_a / (FP64_PEAK_TFLOPS * 1e12)}
+            if (n, D, K, L) == (4096, 8, 2, 1) and not a.no_mean_ite and not a.fp32_kernel:
+                # fp64 VALU and fp64 MFMA share one datapath on gfx950 (profiles/r02_coexec_f64_microbench.txt): the
+                # irreducible fp64 VALU issue time of the Gram build and the MeanITE pass adds to the MFMA time
+                valu_s = GRAM_VALU_US_N4096 * 1e-6 + ITE_MEAN_VALU_US_N4096 * 1e-6
+                ua["ceiling_shared_datapath_units_per_s"] = 1.0 / (flop_a / (FP64_PEAK_TFLOPS * 1e12) + valu_s)
+                ua["ceiling_shared_datapath_note"] = (
+                    f"1 / (flop / peak + {GRAM_VALU_US_N4096} us Gram + {ITE_MEAN_VALU_US_N4096} us MeanITE of pure fp64 VALU "
+                    "issue time per sample at 2.4 GHz, PMC instruction counts of profiles/r02_pmc_gram.md and "
+                    "r02_pmc_ite_mean.md): the MFMA-only ceiling ignores that both instruction classes use the same fp64 units")
+            out["units"]["A"] = ua
+        if world == 1 and not a.no_configs and not a.timing_only:
+            ctx.close()
+            torch.cuda.empty_cache()
+            out["configs"] = {
+                "c2": run_config(gp, synth, np, torch, dev, local_rank, 1024, 4, 1, 8192, 1, False, False, 3, 1,
+                                 "BASELINE configs[1]: Synthetic N=1024 D=4 nU=1 continuous treatment, fp64, unit A with "
+                                 "MeanITE, L=1, 8192 posterior samples per step"),
+                "c5": run_config(gp, synth, np, torch, dev, local_rank, 16384, 16, 4, 64, 1, True, True, 1, 1,
+                                 "BASELINE configs[4] shape on ONE GPU: Synthetic N=16384 D=16 nU=4 binary treatment, "
+                                 "fp32 kernel build + fp64 Cholesky, unit A with MeanITE, doT=1, 64 posterior samples per step"),
+            }
+            for cfg in out["configs"].values():
+                if not cfg["parity"]["ok"]:
+                    rc = 4
         print(json.dumps(out), flush=True)
     if use_dist:
         if rank == 0 and not rehearsal:   # the gathered shards are what a caller would consume: check rank 0's own

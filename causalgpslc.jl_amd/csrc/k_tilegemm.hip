@@ -46,6 +46,22 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define LROW 144                      // padded k-row (doubles)
 #define OPER_LDS (KS * LROW)          // doubles per operand per stage
 #define GEMM_LDS_BYTES (2 * 2 * OPER_LDS * 8)
+#ifndef STRIP_NT
+#define STRIP_NT 2       // A slabs and C tiles are streamed once per launch: non-temporal, so that they do not displace the shared
+                         // B(k, kk) slabs and inv(L_kk) in L2 (measured: fused kernel +1.8 %, profiles/r03_ab_experiments.md)
+#endif
+#ifndef STRIP_DIAG
+#define STRIP_DIAG 0
+#endif
+#ifndef STRIP_PIPE
+#define STRIP_PIPE 0
+#endif
+#ifndef STRIP_STAGGER
+#define STRIP_STAGGER 0
+#endif
+#ifndef FUSE_WD
+#define FUSE_WD 8                      // inv(L) fragments in flight ahead of their MFMAs (strip kernel)
+#endif
 
 __device__ __forceinline__ void tri_decode(int t, int& ii, int& jj) {
     // t = ii(ii+1)/2 + jj, 0 <= jj <= ii
@@ -461,6 +477,271 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------
+// In-panel column update fused with the panel solve, STRIP layout (round 3).
+//     X = C(i,k) - sum_kk A(i,kk) B(k,kk)^T          (K loop, X stays in the accumulators)
+//     L(i,k) = X * inv(L_kk)^T                          (second phase, GemmArgs::F = the inverted diagonal blocks)
+// Wave w owns the 32-row strip [32 w, 32 w + 32) x ALL 128 columns of the tile: acc[m][n][v] =
+// X[32 w + 16 m + (lane & 15)][16 n + 4 v + (lane >> 4)] (2 x 8 accumulators, the same 128 registers as a 64 x 64
+// quadrant).  A lane's accumulator registers are exactly its k-operands of an MFMA over the columns of X, so the
+// second product needs nothing but the wave's own registers and the fragments of inv(L_kk) (L2-resident, shared by the
+// launch): 36 live 16 x 16 blocks of the lower-triangular inverse x 4 k-steps x 2 row blocks = 288 MFMAs on EVERY wave,
+// no LDS hand-over and no barrier.  (With 64 x 64 quadrants the product X(:, 0:64) inv(L)(64:128, 0:64)^T crossed from
+// the left-hand to the right-hand waves through 64 KiB of LDS between two barriers and the waves ran 416 / 160 MFMAs:
+// 64 k clocks of second phase per item against 37 k of MFMA time, profiles/r02_fused_kernel_stamps.md.)
+// Summation order per output element: ascending k in the K loop, ascending column of X in the second phase — the
+// order of the quadrant kernel and of the separate panel product, so the factor is bit-identical.
+// ---------------------------------------------------------------------------------------
+template <int WD>
+__global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    double* lA = smem;                       // [2][KS][LROW]
+    double* lB = smem + 2 * OPER_LDS;        // [2][KS][LROW]
+
+    const long long W = (long long)g.ntiles * g.nbatch;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int gx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+    const long long wq = W >> 3, wrm = W & 7;
+    const long long x0 = xcd * wq + (xcd < wrm ? xcd : wrm);
+    const long long xc = wq + (xcd < wrm ? 1 : 0);
+
+    const int frow_a = lg * LROW + 32 * wave + li;     // + 16 m
+    const int frow_b = lg * LROW + li;                 // + 16 n
+    int loff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = tid + 256 * u;
+        loff[u] = (q >> 6) * LROW + (q & 63) * 2;
+    }
+    const int nslab = (g.k1 - g.k0) * (GP_TS / KS);
+
+    __shared__ int s_ticket;
+    long long it = local;
+#if STRIP_STAGGER > 0
+    if ((int)blockIdx.x >= (G >> 1))
+        for (int i = 0; i < STRIP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+    while (it < xc) {
+        int ticket = 0;
+        if (g.queue && tid == 0) ticket = atomicAdd(&g.queue[xcd], 1);
+        do {
+        const long long item = x0 + it;
+        const int b = (int)(item / g.ntiles);
+        const int t = (int)(item - (long long)b * g.ntiles);
+        int ii, jj;
+        if (g.shape == 0) tri_decode(t, ii, jj);
+        else { ii = t / g.mj; jj = t - ii * g.mj; }
+        const int ti = g.i0 + ii, tj = g.j0 + jj;
+        if (g.sym >= 2 && ti == tj && !(g.short_rows > 0 && ti >= g.short_row0)) break;   // tile_syrk_diag_kernel's
+        // sym == 3: the augmented tile was already updated (it rode with the diagonal item); panel product only
+        const bool no_update = g.sym == 3 && g.short_rows > 0 && ti >= g.short_row0 && tj < g.short_row0;
+
+        double* __restrict__ Ct = tref_tile(g.C, b, ti, tj);
+        // augmented right-hand-side tiles hold `short_rows` live rows: a wave whose strip lies below them only helps
+        // with the staging (its rows keep their zeros: never loaded, never stored)
+        const bool live = !(g.short_rows > 0 && ti >= g.short_row0 && 32 * wave >= g.short_rows);
+        unsigned long long st0 = 0, st1 = 0, st2 = 0;
+        if (GP_DBG_ON(g)) st0 = __builtin_amdgcn_s_memtime();
+
+        d4 acc[2][8];
+        if (live) {
+            const double* __restrict__ Cl = Ct + (lg * GP_TS + 32 * wave + li);
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#if STRIP_NT >= 2
+                        acc[m][n][v] = __builtin_nontemporal_load(Cl + (16 * n + 4 * v) * GP_TS + 16 * m);
+#else
+                        acc[m][n][v] = Cl[(16 * n + 4 * v) * GP_TS + 16 * m];
+#endif
+        }
+
+        if (nslab > 0 && !no_update) {
+            d2 ra[4], rb[4], ra2[4], rb2[4];
+            auto gload = [&](int s, d2 (&xa)[4], d2 (&xb)[4]) {
+                const int kk = g.k0 + (s >> 3);
+                const int so = (s & 7) * (KS * GP_TS);
+#if STRIP_DIAG == 2
+                const double* pa = tref_tile(g.A, b, ti, g.k0);
+#else
+                const double* pa = tref_tile(g.A, b, ti, kk) + so;
+#endif
+#if STRIP_DIAG == 1 || STRIP_DIAG == 2
+                const double* pb = tref_tile(g.B, b, tj, g.k0);
+#else
+                const double* pb = tref_tile(g.B, b, tj, kk) + so;
+#endif
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#if STRIP_NT >= 1
+                    xa[u] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2));
+#else
+                    xa[u] = *reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2);
+#endif
+                    xb[u] = *reinterpret_cast<const d2*>(pb + (tid + 256 * u) * 2);
+                }
+            };
+            auto lstore = [&](int buf, const d2 (&xa)[4], const d2 (&xb)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    *reinterpret_cast<d2*>(lA + buf * OPER_LDS + loff[u]) = xa[u];
+                    *reinterpret_cast<d2*>(lB + buf * OPER_LDS + loff[u]) = xb[u];
+                }
+            };
+            auto compute = [&](int buf) {
+                if (!live) return;
+                const double* pa = lA + buf * OPER_LDS + frow_a;
+                const double* pb = lB + buf * OPER_LDS + frow_b;
+#if STRIP_PIPE == 0
+#pragma unroll
+                for (int ks = 0; ks < KS / 4; ++ks) {
+                    double af[2], bf[8];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) af[m] = pa[ks * 4 * LROW + 16 * m];
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) bf[n] = pb[ks * 4 * LROW + 16 * n];
+#pragma unroll
+                    for (int n = 0; n < 8; ++n)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][n] = mfma_step<1>(bf[n], af[m], acc[m][n]);
+                }
+#else
+                // the first fragments of k-step ks + 1 (both row blocks, PN column blocks) are requested before the MFMAs of
+                // k-step ks are issued; the other column blocks arrive under the first 2 PN MFMAs of their k-step
+                constexpr int PN = STRIP_PIPE;
+                double afn[2], bfn[PN];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) afn[m] = pa[16 * m];
+#pragma unroll
+                for (int n = 0; n < PN; ++n) bfn[n] = pb[16 * n];
+#pragma unroll
+                for (int ks = 0; ks < KS / 4; ++ks) {
+                    double af[2], bf[8];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) af[m] = afn[m];
+#pragma unroll
+                    for (int n = 0; n < PN; ++n) bf[n] = bfn[n];
+#pragma unroll
+                    for (int n = PN; n < 8; ++n) bf[n] = pb[ks * 4 * LROW + 16 * n];
+                    if (ks + 1 < KS / 4) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) afn[m] = pa[(ks + 1) * 4 * LROW + 16 * m];
+#pragma unroll
+                        for (int n = 0; n < PN; ++n) bfn[n] = pb[(ks + 1) * 4 * LROW + 16 * n];
+                    }
+#pragma unroll
+                    for (int n = 0; n < 8; ++n)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][n] = mfma_step<1>(bf[n], af[m], acc[m][n]);
+                }
+#endif
+            };
+            gload(0, ra, rb);
+            lstore(0, ra, rb);
+            gload(1, ra, rb);          // nslab is a multiple of 8
+            __syncthreads();
+            if (GP_DBG_ON(g)) st1 = __builtin_amdgcn_s_memtime();
+            for (int s = 0; s < nslab; s += 2) {
+                if (s + 2 < nslab) gload(s + 2, ra2, rb2);
+                compute(0);
+                lstore(1, ra, rb);
+                __syncthreads();
+                if (s + 3 < nslab) gload(s + 3, ra, rb);
+                compute(1);
+                if (s + 2 < nslab) lstore(0, ra2, rb2);
+                __syncthreads();
+            }
+        }
+        if (GP_DBG_ON(g)) st2 = __builtin_amdgcn_s_memtime();
+
+        if (live) {
+            // fragment (nc, n, v) of W = inv(L_kk): W[16 nc + li][16 n + 4 v + lg], element (c, c') at c' * 128 + c
+            const double* __restrict__ Wl = tref_tile(g.F, b, 0, g.fk) + (lg * GP_TS + li);
+            double* __restrict__ Co = Ct + (lg * GP_TS + 32 * wave + li);
+            // the 144 live fragments in the order of use, WD groups (WD x 128 MFMA clocks) ahead through a register ring
+            double wn[WD];
+            int pc = 0, pn = 0, pv = 0;        // next fragment to request (compile-time after unrolling)
+#pragma unroll
+            for (int q = 0; q < WD; ++q) {
+                wn[q] = Wl[(16 * pn + 4 * pv) * GP_TS + 16 * pc];
+                if (++pv == 4) { pv = 0; if (++pn > pc) { pn = 0; ++pc; } }
+            }
+            int q = 0;
+#pragma unroll
+            for (int nc = 0; nc < 8; ++nc) {
+                d4 st[2];
+                st[0] = (d4){0.0, 0.0, 0.0, 0.0};
+                st[1] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    if (n <= nc) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const double w = wn[q % WD];
+                            if (pc < 8) {
+                                wn[q % WD] = Wl[(16 * pn + 4 * pv) * GP_TS + 16 * pc];
+                                if (++pv == 4) { pv = 0; if (++pn > pc) { pn = 0; ++pc; } }
+                            }
+                            ++q;
+#if STRIP_DIAG == 3
+                            st[0][v] += w * acc[0][n][v]; st[1][v] += w * acc[1][n][v];   // timing only: no second-phase MFMAs
+#else
+                            st[0] = mfma_step<0>(w, acc[0][n][v], st[0]);
+                            st[1] = mfma_step<0>(w, acc[1][n][v], st[1]);
+#endif
+                        }
+                    }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+#if STRIP_NT >= 2
+                    __builtin_nontemporal_store(st[0][v], Co + (16 * nc + 4 * v) * GP_TS);
+                    __builtin_nontemporal_store(st[1][v], Co + (16 * nc + 4 * v) * GP_TS + 16);
+#else
+                    Co[(16 * nc + 4 * v) * GP_TS] = st[0][v];
+                    Co[(16 * nc + 4 * v) * GP_TS + 16] = st[1][v];
+#endif
+                }
+            }
+        }
+        if (GP_DBG_ON(g)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+            if (tid == 0) {
+                unsigned long long* d = g.dbg + (size_t)item * 8;
+                d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3;
+                d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                d[6] = __builtin_amdgcn_s_memrealtime();
+                d[7] = blockIdx.x;
+            }
+        }
+        } while (0);
+        if (g.queue) {
+            if (tid == 0) s_ticket = ticket;
+            __syncthreads();
+            it = (long long)gx + s_ticket;
+            __syncthreads();
+        } else {
+            it += gx;
+        }
+    }
+    if (g.queue && tid == 0) {
+        __threadfence();
+        if (atomicAdd(&g.queue[8 + xcd], 1) == gx - 1) {
+            g.queue[xcd] = 0;
+            g.queue[8 + xcd] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Diagonal tiles of a symmetric update:  C(t, t) -= sum_kk A(t, kk) A(t, kk)^T, lower triangle only.
 // Work item = (diagonal tile t in [0, mi), batch element).  Wave w owns sub-tile rows w and 7 - w of the
 // 8 x 8 grid of 16 x 16 sub-tiles: (w, 0..w) and (7 - w, 0..7 - w), 9 sub-tiles, 9 accumulators.  Both MFMA
@@ -676,7 +957,14 @@ void launch_tile_gemm(const GemmArgs& g, hipStream_t st) {
     }
 #endif
     if (g.fuse && g.accumulate) {
-        launch_one<1, 0, 1>(g, grid, st);
+        static const int strip = diag_env("GPSLC_FUSE_STRIP", 1);
+        if (strip) {
+            static DeviceOnce once;
+            lds_opt_in(once, (const void*)tile_fused_strip_kernel<FUSE_WD>, GEMM_LDS_BYTES);
+            hipLaunchKernelGGL((tile_fused_strip_kernel<FUSE_WD>), dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
+        } else {
+            launch_one<1, 0, 1>(g, grid, st);
+        }
     } else {
         if (g.accumulate) launch_one<1, 0>(g, grid, st); else launch_one<0, 0>(g, grid, st);
     }
