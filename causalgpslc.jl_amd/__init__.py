@@ -17,4 +17,4 @@ from .inference import (  # noqa: F401
     gpslc, Posterior, prepareData, generateSigmaU, removeAdjacent, getPriorParameters, getHyperParameters,
     toMatrixModel,
 )
-from .sharded import predict_sharded, predict_sharded_pack, shard_range  # noqa: F401
+from .sharded import predict_sharded, predict_sharded_full, predict_sharded_pack, shard_range, ShardedResult  # noqa: F401

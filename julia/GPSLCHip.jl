@@ -1,0 +1,591 @@
+# GPSLCHip.jl — the reference-side binding of libgpslc_hip.so (include/gpslc_hip.h).
+#
+# How a CausalGPSLC.jl maintainer uses it: in src/CausalGPSLC.jl, add
+#     include("GPSLCHip.jl")
+# AFTER the existing includes (types.jl, utils.jl, kernel.jl, likelihood.jl, estimation.jl, driver.jl,
+# prediction.jl, model_likelihood.jl must be loaded first: the methods below have the SAME signatures as the
+# reference's and therefore replace their bodies).  Nothing in src/inference.jl or src/prediction.jl changes: they
+# only use rbfKernelLog / processCov (src/inference.jl:225-227, 286-287, 343-344), sampleITE, getN,
+# getNumPosteriorSamples and Gen addresses.
+#
+# Part 1 (module GPSLCHip) binds EVERY function the header declares, one thin wrapper per symbol — the `ccall`
+# type tuples are checked mechanically against include/gpslc_hip.h and causalgpslc.jl_amd/_lib.py by
+# tests/test_julia_binding.py (arity, type order, struct layouts), because Julia is not available in the build
+# pipeline and this file cannot be executed there.
+# Part 2 re-defines the reference's hot-path functions on top of those wrappers.
+#
+# Conventions (header comment of gpslc_hip.h): column-major Float64 everywhere (Julia's own layout), Bool
+# treatments pre-converted to 0.0 / 1.0, status 0 = ok, > 0 = PosDefException(info), < 0 = error.
+
+module GPSLCHip
+
+using LinearAlgebra: PosDefException
+
+const lib = get(ENV, "GPSLC_HIP_LIB", joinpath(@__DIR__, "..", "deps", "libgpslc_hip.so"))
+
+# ---- gpslc_node / gpslc_pack_header: same field order and types as the C structs ------------------------------
+struct GPSLCNode
+    nF::Int32
+    reserved::Int32
+    F::Ptr{Float64}
+    ls::Ptr{Float64}
+    scale::Float64
+    noise::Float64
+    target::Ptr{Float64}
+end
+
+struct PackHeader
+    n::Int64
+    nX::Int64
+    nU::Int64
+    S::Int64
+    binary_t::Int64
+    reserved::Int64
+    hyper::NTuple{7,Float64}
+end
+PackHeader() = PackHeader(0, 0, 0, 0, 0, 0, ntuple(_ -> 0.0, 7))
+
+const FLAG_DEFAULT = UInt32(0)
+const FLAG_PROFILE = UInt32(1)
+const FLAG_FP32_KERNEL = UInt32(2)
+
+# ---- context --------------------------------------------------------------------------------------------------
+mutable struct Ctx
+    h::Ptr{Cvoid}
+    n::Int
+    nX::Int
+    nU::Int
+    data::Any                      # (X, T, Y) as handed to set_data! (Float64 host copies), or nothing
+    function Ctx(n::Integer, nX::Integer, nU::Integer; device::Integer=0, flags::Integer=FLAG_DEFAULT)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        st = ccall((:gpslc_create, lib), Cint, (Ref{Ptr{Cvoid}}, Cint, Int64, Int32, Int32, UInt32),
+                   r, device, n, nX, nU, flags)
+        st == 0 || error("gpslc_create: status $st")
+        c = new(r[], n, nX, nU, nothing)
+        finalizer(destroy!, c)
+        c
+    end
+end
+
+function destroy!(c::Ctx)
+    if c.h != C_NULL
+        ccall((:gpslc_destroy, lib), Cint, (Ptr{Cvoid},), c.h)
+        c.h = C_NULL
+    end
+    nothing
+end
+
+last_error(c::Ctx) = unsafe_string(ccall((:gpslc_last_error, lib), Cstring, (Ptr{Cvoid},), c.h))
+version() = unsafe_string(ccall((:gpslc_version, lib), Cstring, ()))
+
+"""0 = ok; > 0 = the 1-based pivot at which a Cholesky broke down -> PosDefException, what PDMats raises inside
+Gen.mvnormal; < 0 = error with the library's message."""
+function check(c::Ctx, st::Integer)
+    st == 0 && return nothing
+    st > 0 && throw(PosDefException(st))
+    error("gpslc status $st: " * last_error(c))
+end
+
+# marshalling: Float64 column-major arrays; Bool / Int inputs promote as they do on subtraction (src/kernel.jl:17)
+f64(x::Nothing) = nothing
+f64(x::Array{Float64}) = x
+f64(x::AbstractArray) = convert(Array{Float64}, collect(x))
+f64(x::Number) = Float64[x]
+ptr(::Nothing) = Ptr{Float64}(C_NULL)
+ptr(x::Array{Float64}) = pointer(x)
+
+function set_data!(c::Ctx, X, T, Y)
+    Xf, Tf, Yf = f64(X), f64(T), f64(Y)
+    GC.@preserve Xf Tf Yf check(c, ccall((:gpslc_set_data, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), c.h, ptr(Xf), ptr(Tf), ptr(Yf)))
+    c.data = (Xf, Tf, Yf)
+    nothing
+end
+
+"""Device pointers (AMDGPU.jl ROCArray memory on the ctx's device)."""
+set_data_dev!(c::Ctx, X::Ptr{Float64}, T::Ptr{Float64}, Y::Ptr{Float64}) = check(c, ccall((:gpslc_set_data_dev, lib), Cint,
+    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), c.h, X, T, Y))
+
+set_tuning!(c::Ctx; max_batch::Integer=0, panel_tiles::Integer=0, n_streams::Integer=0) = check(c,
+    ccall((:gpslc_set_tuning, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Int32), c.h, max_batch, panel_tiles, n_streams))
+
+# ---- src/kernel.jl ----------------------------------------------------------------------------------------------
+function rbf_log(c::Ctx, X1::Array{Float64}, X2::Array{Float64}, ls::Vector{Float64})
+    n, d = size(X1, 1), size(X1, 2)
+    out = Matrix{Float64}(undef, n, n)
+    GC.@preserve X1 X2 ls out check(c, ccall((:gpslc_rbf_log, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int32, Ptr{Float64}, Int32, Ptr{Float64}),
+        c.h, pointer(X1), pointer(X2), n, d, pointer(ls), length(ls), pointer(out)))
+    out
+end
+
+rbf_log_dev(c::Ctx, X1::Ptr{Float64}, X2::Ptr{Float64}, n::Integer, d::Integer, ls::Ptr{Float64}, ls_len::Integer,
+            out::Ptr{Float64}) = check(c, ccall((:gpslc_rbf_log_dev, lib), Cint,
+    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int32, Ptr{Float64}, Int32, Ptr{Float64}),
+    c.h, X1, X2, n, d, ls, ls_len, out))
+
+function process_cov(c::Ctx, logcov::Array{Float64}, scale::Float64, noise::Float64)
+    n = size(logcov, 1)
+    out = similar(logcov)
+    GC.@preserve logcov out check(c, ccall((:gpslc_process_cov, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Float64, Float64, Ptr{Float64}),
+        c.h, pointer(logcov), n, scale, noise, pointer(out)))
+    out
+end
+
+process_cov_dev(c::Ctx, logcov::Ptr{Float64}, n::Integer, scale::Float64, noise::Float64, out::Ptr{Float64}) =
+    check(c, ccall((:gpslc_process_cov_dev, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Float64, Float64, Ptr{Float64}), c.h, logcov, n, scale, noise, out))
+
+# ---- Gen nodes (src/model_likelihood.jl, src/model_prior.jl) ----------------------------------------------------
+"""log N(Y; 0, Ycov) of the :Y node for S parameter sets (src/model_likelihood.jl:83-120)."""
+function y_logpdf(c::Ctx, S::Integer, U, X_or_nothing, Y_or_nothing, uyLS, xyLS, tyLS::Vector{Float64},
+                  yScale::Vector{Float64}, yNoise::Vector{Float64})
+    out = Vector{Float64}(undef, S)
+    Uf, Xf, Yf, uy, xy = f64(U), f64(X_or_nothing), f64(Y_or_nothing), f64(uyLS), f64(xyLS)
+    GC.@preserve Uf Xf Yf uy xy tyLS yScale yNoise out check(c, ccall((:gpslc_y_logpdf, lib), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, S, ptr(Uf), ptr(Xf), ptr(Yf), ptr(uy), ptr(xy), pointer(tyLS), pointer(yScale), pointer(yNoise),
+        pointer(out)))
+    out
+end
+
+"""log N(target; 0, scale exp.(rbfKernelLog(F, F, ls)) + noise I) for S parameter sets: :X => k => :X, :T / :logitT."""
+function gp_logpdf(c::Ctx, S::Integer, nF::Integer, F::Array{Float64}, f_shared::Bool, ls::Array{Float64},
+                   scale::Vector{Float64}, noise::Vector{Float64}, target::Array{Float64}, t_shared::Bool)
+    out = Vector{Float64}(undef, S)
+    GC.@preserve F ls scale noise target out check(c, ccall((:gpslc_gp_logpdf, lib), Cint,
+        (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Int32, Ptr{Float64}),
+        c.h, S, nF, pointer(F), f_shared ? 1 : 0, pointer(ls), pointer(scale), pointer(noise), pointer(target),
+        t_shared ? 1 : 0, pointer(out)))
+    out
+end
+
+"""The fused whole-model score: every node one Gen `update` re-scores (src/model.jl:11-131), one call.  The arrays
+the nodes point into must be kept alive by the caller (GC.@preserve) for the duration of the call."""
+function nodes_logpdf(c::Ctx, nodes::Vector{GPSLCNode})
+    out = Vector{Float64}(undef, length(nodes))
+    GC.@preserve nodes out check(c, ccall((:gpslc_nodes_logpdf, lib), Cint,
+        (Ptr{Cvoid}, Int32, Ptr{GPSLCNode}, Ptr{Float64}), c.h, length(nodes), pointer(nodes), pointer(out)))
+    out
+end
+
+"""draws[:, i] = chol(K_i) * target_i (target = the caller's standard normals): Gen's mvnormal(zeros(n), cov) inside
+elliptical_slice(trace, :logitT, zeros(n), logitTCov) (src/inference.jl:225-232, 286-289, 343-348)."""
+function nodes_draw(c::Ctx, nodes::Vector{GPSLCNode}; want_logpdf::Bool=false)
+    draws = Matrix{Float64}(undef, c.n, length(nodes))
+    lp = want_logpdf ? Vector{Float64}(undef, length(nodes)) : nothing
+    GC.@preserve nodes draws lp check(c, ccall((:gpslc_nodes_draw, lib), Cint,
+        (Ptr{Cvoid}, Int32, Ptr{GPSLCNode}, Ptr{Float64}, Ptr{Float64}),
+        c.h, length(nodes), pointer(nodes), pointer(draws), ptr(lp)))
+    want_logpdf ? (draws, lp) : draws
+end
+
+"""log N(x_s; 0, covscale_s * cov): the :U => u => :U nodes (src/model_likelihood.jl:4-10).  Pass `cov` once
+(S = 0 just hands it over), then `nothing`."""
+function mvn_logpdf(c::Ctx, cov, covscale, x)
+    S = x === nothing ? 0 : size(x, 2)
+    out = Vector{Float64}(undef, S)
+    cf, sf, xf = f64(cov), f64(covscale), f64(x)
+    GC.@preserve cf sf xf out check(c, ccall((:gpslc_mvn_logpdf, lib), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, S, ptr(cf), ptr(sf), ptr(xf), pointer(out)))
+    out
+end
+
+# ---- the posterior pack: extractParameters stacked for nBurnIn:stepSize:nOuter (src/utils.jl:92-124) ------------
+struct Pack
+    U::Union{Array{Float64,3},Nothing}        # n x nU x S
+    uyLS::Union{Matrix{Float64},Nothing}      # nU x S
+    xyLS::Union{Matrix{Float64},Nothing}      # nX x S
+    tyLS::Vector{Float64}                     # S
+    yNoise::Vector{Float64}
+    yScale::Vector{Float64}
+end
+
+# ---- src/estimation.jl, src/driver.jl, src/prediction.jl --------------------------------------------------------
+"""The ensemble driver.  Returns (meanSATE S x L, varSATE S x L, meanITE n x S x L | nothing, ite L x n x (S*spp) |
+nothing).  `z`: the caller's standard normals n x spp x S x L (Julia's RNG stays in charge) or nothing + `seed`."""
+function predict(c::Ctx, p::Pack, doT::Vector{Float64}, pred_noise::Float64; spp::Integer=0, seed::Integer=0,
+                 z=nothing, want_mean_ite::Bool=false, want_draws::Bool=false)
+    S, L, n = length(p.tyLS), length(doT), c.n
+    mS, vS = Matrix{Float64}(undef, S, L), Matrix{Float64}(undef, S, L)
+    mI = want_mean_ite ? Array{Float64}(undef, n, S, L) : nothing
+    dr = want_draws ? Array{Float64}(undef, L, n, S * spp) : nothing
+    zf = f64(z)
+    GC.@preserve p doT zf mS vS mI dr check(c, ccall((:gpslc_predict, lib), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Int32, Ptr{Float64}, Float64, Int32, UInt64, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, S, ptr(p.U), ptr(p.uyLS), ptr(p.xyLS), pointer(p.tyLS), pointer(p.yScale), pointer(p.yNoise),
+        L, pointer(doT), pred_noise, spp, seed, ptr(zf),
+        pointer(mS), pointer(vS), ptr(mI), ptr(dr)))
+    mS, vS, mI, dr
+end
+
+"""As `predict`, every array argument a DEVICE pointer (ROCArray memory); outputs stay in HBM."""
+predict_dev(c::Ctx, S::Integer, U::Ptr{Float64}, uyLS::Ptr{Float64}, xyLS::Ptr{Float64}, tyLS::Ptr{Float64},
+            yScale::Ptr{Float64}, yNoise::Ptr{Float64}, L::Integer, doT::Ptr{Float64}, pred_noise::Float64,
+            spp::Integer, seed::Integer, z::Ptr{Float64}, meanSATE::Ptr{Float64}, varSATE::Ptr{Float64},
+            meanITE::Ptr{Float64}, ite_draws::Ptr{Float64}) = check(c, ccall((:gpslc_predict_dev, lib), Cint,
+    (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+     Int32, Ptr{Float64}, Float64, Int32, UInt64, Ptr{Float64},
+     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+    c.h, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, pred_noise, spp, seed, z, meanSATE, varSATE, meanITE, ite_draws))
+
+"""ITEDistributions with the reference's output layout: MeanITEs S x n, CovITEs S x n x n (jitter included)."""
+function ite_distributions(c::Ctx, p::Pack, doT::Float64, pred_noise::Float64; want_cov::Bool=true)
+    S, n = length(p.tyLS), c.n
+    M = Matrix{Float64}(undef, S, n)
+    Cv = want_cov ? Array{Float64}(undef, S, n, n) : nothing
+    GC.@preserve p M Cv check(c, ccall((:gpslc_ite_distributions, lib), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Float64, Float64, Ptr{Float64}, Ptr{Float64}),
+        c.h, S, ptr(p.U), ptr(p.uyLS), ptr(p.xyLS), pointer(p.tyLS), pointer(p.yScale), pointer(p.yNoise),
+        doT, pred_noise, pointer(M), ptr(Cv)))
+    M, Cv
+end
+
+"""The seven dense blocks of likelihoodDistribution for one parameter set (src/likelihood.jl:8-174)."""
+function likelihood_distribution(c::Ctx, U, uyLS, xyLS, tyLS::Float64, yScale::Float64, yNoise::Float64, doT::Float64)
+    n = c.n
+    blocks = [Matrix{Float64}(undef, n, n) for _ in 1:7]
+    Uf, uy, xy = f64(U), f64(uyLS), f64(xyLS)
+    GC.@preserve Uf uy xy blocks check(c, ccall((:gpslc_likelihood_distribution, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Float64, Float64,
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, ptr(Uf), ptr(uy), ptr(xy), tyLS, yScale, yNoise, doT,
+        pointer(blocks[1]), pointer(blocks[2]), pointer(blocks[3]), pointer(blocks[4]), pointer(blocks[5]),
+        pointer(blocks[6]), pointer(blocks[7])))
+    blocks      # CovWW, CovWWs, CovWWp, CovC11, CovC12, CovC21, CovC22
+end
+
+"""SATEsamples: mean[j] + var[j] * z — the variance used as sigma, as the reference does (src/estimation.jl:159)."""
+function sate_samples(meanSATE::Vector{Float64}, varSATE::Vector{Float64}, spp::Integer; seed::Integer=0, z=nothing)
+    S = length(meanSATE)
+    out = Vector{Float64}(undef, S * spp)
+    zf = f64(z)
+    GC.@preserve meanSATE varSATE zf out begin
+        st = ccall((:gpslc_sate_samples, lib), Cint,
+            (Ptr{Float64}, Ptr{Float64}, Int64, Int32, UInt64, Ptr{Float64}, Ptr{Float64}),
+            pointer(meanSATE), pointer(varSATE), S, spp, seed, ptr(zf), pointer(out))
+        st == 0 || error("gpslc_sate_samples: status $st")
+    end
+    out
+end
+
+"""Per-individual mean and the two type-7 quantiles of an n x m sample matrix (src/driver.jl:129-149)."""
+function summarize(c::Ctx, samples::Matrix{Float64}, credible_interval::Float64)
+    n, m = size(samples)
+    mean, lower, upper = Vector{Float64}(undef, n), Vector{Float64}(undef, n), Vector{Float64}(undef, n)
+    GC.@preserve samples mean lower upper check(c, ccall((:gpslc_summarize, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, pointer(samples), n, m, credible_interval, pointer(mean), pointer(lower), pointer(upper)))
+    mean, lower, upper
+end
+
+summarize_dev(c::Ctx, samples::Ptr{Float64}, n::Integer, m::Integer, row_stride::Integer, col_stride::Integer,
+              credible_interval::Float64, mean::Ptr{Float64}, lower::Ptr{Float64}, upper::Ptr{Float64}) =
+    check(c, ccall((:gpslc_summarize_dev, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, samples, n, m, row_stride, col_stride, credible_interval, mean, lower, upper))
+
+"""1-based failing pivot (0 = ok) of every posterior sample of the last call."""
+function last_info(c::Ctx, S::Integer)
+    info = Vector{Int32}(undef, S)
+    GC.@preserve info check(c, ccall((:gpslc_last_info, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}, Int64), c.h, pointer(info), S))
+    info
+end
+
+# ---- posterior pack file (replaces Serialization for the prediction path, src/io.jl:14-34) -----------------------
+function pack_save(path::AbstractString, h::PackHeader, X, T, Y, p::Pack)
+    Xf, Tf, Yf = f64(X), f64(T), f64(Y)
+    GC.@preserve Xf Tf Yf p begin
+        st = ccall((:gpslc_pack_save, lib), Cint,
+            (Cstring, Ref{PackHeader}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+            path, Ref(h), ptr(Xf), ptr(Tf), ptr(Yf), ptr(p.U), ptr(p.uyLS), ptr(p.xyLS), pointer(p.tyLS),
+            pointer(p.yNoise), pointer(p.yScale))
+        st == 0 || error("gpslc_pack_save: status $st")
+    end
+    nothing
+end
+
+function pack_read_header(path::AbstractString)
+    h = Ref(PackHeader())
+    st = ccall((:gpslc_pack_read_header, lib), Cint, (Cstring, Ref{PackHeader}), path, h)
+    st == 0 || error("gpslc_pack_read_header: status $st")
+    h[]
+end
+
+"""Data and the posterior samples [s0, s1) (0-based, half-open) of a pack: what one rank of a sharded prediction loads."""
+function pack_load(path::AbstractString, s0::Integer, s1::Integer)
+    h = pack_read_header(path)
+    n, nX, nU, S = h.n, h.nX, h.nU, s1 - s0
+    X = nX > 0 ? Matrix{Float64}(undef, n, nX) : nothing
+    T, Y = Vector{Float64}(undef, n), Vector{Float64}(undef, n)
+    U = nU > 0 ? Array{Float64}(undef, n, nU, S) : nothing
+    uy = nU > 0 ? Matrix{Float64}(undef, nU, S) : nothing
+    xy = nX > 0 ? Matrix{Float64}(undef, nX, S) : nothing
+    ty, yn, ys = Vector{Float64}(undef, S), Vector{Float64}(undef, S), Vector{Float64}(undef, S)
+    GC.@preserve X T Y U uy xy ty yn ys begin
+        st = ccall((:gpslc_pack_load, lib), Cint,
+            (Cstring, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+            path, s0, s1, ptr(X), pointer(T), pointer(Y), ptr(U), ptr(uy), ptr(xy), pointer(ty), pointer(yn), pointer(ys))
+        st == 0 || error("gpslc_pack_load: status $st")
+    end
+    h, X, T, Y, Pack(U, uy, xy, ty, yn, ys)
+end
+
+# ---- measurement hooks ------------------------------------------------------------------------------------------
+profile_reset!(c::Ctx) = check(c, ccall((:gpslc_profile_reset, lib), Cint, (Ptr{Cvoid},), c.h))
+
+function profile_get(c::Ctx)
+    l, ms, fl = Ref{Int64}(0), Ref{Float64}(0.0), Ref{Float64}(0.0)
+    check(c, ccall((:gpslc_profile_get, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Float64}, Ref{Float64}), c.h, l, ms, fl))
+    l[], ms[], fl[]
+end
+
+function profile_get_class(c::Ctx, kernel_class::Integer)
+    l, ms, fl = Ref{Int64}(0), Ref{Float64}(0.0), Ref{Float64}(0.0)
+    check(c, ccall((:gpslc_profile_get_class, lib), Cint, (Ptr{Cvoid}, Int32, Ref{Int64}, Ref{Float64}, Ref{Float64}),
+                   c.h, kernel_class, l, ms, fl))
+    l[], ms[], fl[]
+end
+
+# ---- the helpers the method bodies of part 2 use -----------------------------------------------------------------
+"""The context of the kernel-only calls (rbfKernelLog / processCov carry no data set): created on first use."""
+const KCTX = Ref{Union{Ctx,Nothing}}(nothing)
+function kctx()
+    KCTX[] === nothing && (KCTX[] = Ctx(1, 0, 0))
+    KCTX[]::Ctx
+end
+
+end # module GPSLCHip
+
+
+# =====================================================================================================================
+# Part 2 — the reference's functions, same signatures, bodies on the GPU.  (Evaluated in CausalGPSLC's namespace:
+# GPSLCObject, Intervention, Confounders, ... are the reference's own types, src/types.jl.)
+# =====================================================================================================================
+
+import LinearAlgebra
+
+# ---- one Ctx + one posterior pack per GPSLCObject (the object is immutable: cache by identity) -------------------
+const _GPSLC_CTX = IdDict{Any,GPSLCHip.Ctx}()
+const _GPSLC_PACK = IdDict{Any,GPSLCHip.Pack}()
+
+"""ctx(g): the device context holding g.X, g.T, g.Y (src/types.jl:249-258), created on first use."""
+function ctx(g::GPSLCObject)
+    get!(_GPSLC_CTX, g) do
+        nX = g.X === nothing ? 0 : getNX(g)
+        nU = getNU(g) === nothing ? 0 : getNU(g)
+        c = GPSLCHip.Ctx(getN(g), nX, nU)
+        GPSLCHip.set_data!(c, g.X, g.T, g.Y)           # Bool treatments become 0.0 / 1.0 here
+        c
+    end
+end
+
+"""posterior_pack(g): extractParameters (src/utils.jl:92-124) for i in nBurnIn:stepSize:nOuter
+(src/estimation.jl:72, 78 — the burn-in index itself included), stacked along a trailing sample axis."""
+function posterior_pack(g::GPSLCObject)
+    get!(_GPSLC_PACK, g) do
+        idx = g.hyperparams.nBurnIn:g.hyperparams.stepSize:g.hyperparams.nOuter
+        ps = [extractParameters(g, i) for i in idx]            # (uyLS, xyLS, tyLS, yNoise, yScale, U)
+        hasU, hasX = ps[1][1] !== nothing, ps[1][2] !== nothing
+        GPSLCHip.Pack(hasU ? cat((Float64.(p[6]) for p in ps)...; dims=3) : nothing,
+                      hasU ? reduce(hcat, (Float64.(p[1]) for p in ps)) : nothing,
+                      hasX ? reduce(hcat, (Float64.(vec(p[2])) for p in ps)) : nothing,
+                      Float64[p[3] for p in ps], Float64[p[4] for p in ps], Float64[p[5] for p in ps])
+    end
+end
+
+_ls(LS::Number) = Float64[LS]
+_ls(LS) = GPSLCHip.f64(vec(collect(LS)))
+_mat(X::AbstractMatrix) = GPSLCHip.f64(X)
+_mat(X::AbstractVector) = reshape(GPSLCHip.f64(X), :, 1)
+
+# ---- src/kernel.jl ------------------------------------------------------------------------------------------------
+function rbfKernelLogScalar(Xi::SupportedRBFVector, Xiprime::SupportedRBFVector, LS::SupportedRBFLengthscale)   # :13-19
+    @assert (size(LS, 1) == size(Xi, 1) || size(LS) == ()) "vector lengthscale doesn't match individual"
+    x1 = reshape(GPSLCHip.f64(collect(Xi)), 1, :)
+    x2 = reshape(GPSLCHip.f64(collect(Xiprime)), 1, :)
+    GPSLCHip.rbf_log(GPSLCHip.kctx(), x1, x2, _ls(LS))[1, 1]
+end
+
+function rbfKernelLog(X1::SupportedRBFMatrix, X2::SupportedRBFMatrix, LS::SupportedRBFLengthscale)              # :24-32
+    @assert size(X1) == size(X2) "X1 and X2 are different sizes!"
+    GPSLCHip.rbf_log(GPSLCHip.kctx(), _mat(collect(X1)), _mat(collect(X2)), _ls(LS))
+end
+
+function rbfKernelLog(X1::SupportedRBFData, X2::SupportedRBFData, LS::SupportedRBFLengthscale)                  # :34-42
+    @assert size(X1) == size(X2) "X1 and X2 are different sizes!"
+    # Vector{Vector}: individual i is X1[i]; stack the individuals as rows
+    A = permutedims(reduce(hcat, (GPSLCHip.f64(collect(x)) for x in X1)))
+    B = permutedims(reduce(hcat, (GPSLCHip.f64(collect(x)) for x in X2)))
+    GPSLCHip.rbf_log(GPSLCHip.kctx(), Matrix{Float64}(A), Matrix{Float64}(B), _ls(LS))
+end
+
+function processCov(logCov::Union{Float64,Array{Float64}}, scale::Union{Float64,Array{Float64}}, noise::Float64)  # :53-55
+    (logCov isa Float64 || !(scale isa Float64)) && return exp.(logCov) * scale + 1LinearAlgebra.I * noise   # scalar / array-scale forms stay on the host
+    GPSLCHip.process_cov(GPSLCHip.kctx(), logCov, scale, noise)
+end
+
+function processCov(logCov::Union{Float64,Array{Float64}}, scale::Float64)                                        # :57-59
+    logCov isa Float64 && return exp(logCov) * scale
+    GPSLCHip.process_cov(GPSLCHip.kctx(), logCov, scale, 0.0)
+end
+
+# ---- src/likelihood.jl: the four methods differ only in which of U / X are `nothing` ------------------------------
+function _likelihood_blocks(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y, doT)
+    n = size(Y, 1)
+    c = GPSLCHip.Ctx(n, X === nothing ? 0 : size(X, 2), U === nothing ? 0 : size(U, 2))
+    GPSLCHip.set_data!(c, X, T, Y)
+    b = GPSLCHip.likelihood_distribution(c, U, uyLS, xyLS, tyLS, yScale, yNoise, Float64(doT))
+    GPSLCHip.destroy!(c)
+    Y, b[1], b[2], b[3], b[4], b[5], b[6], b[7]        # Y, CovWW, CovWWs, CovWWp, CovC11, CovC12, CovC21, CovC22 (:51)
+end
+
+function likelihoodDistribution(uyLS::Vector{Float64}, xyLS::Array{Float64}, tyLS::Float64, yNoise::Float64, yScale::Float64,
+                                U::Confounders, X::Covariates, T::Treatment, Y::Outcome, doT::Intervention)      # :8-52
+    n = size(Y, 1)
+    @assert size(U, 1) == n
+    @assert size(X, 1) == n
+    @assert size(T, 1) == n
+    _likelihood_blocks(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y, doT)
+end
+
+function likelihoodDistribution(uyLS::Vector{Float64}, xyLS::Nothing, tyLS::Float64, yNoise::Float64, yScale::Float64,
+                                U::Confounders, X::Nothing, T::Treatment, Y::Outcome, doT::Intervention)         # :55-94
+    n = size(Y, 1)
+    @assert size(U, 1) == n
+    @assert size(T, 1) == n
+    _likelihood_blocks(uyLS, nothing, tyLS, yNoise, yScale, U, nothing, T, Y, doT)
+end
+
+function likelihoodDistribution(uyLS::Nothing, xyLS::Vector{Float64}, tyLS::Float64, yNoise::Float64, yScale::Float64,
+                                U::Nothing, X::Covariates, T::Treatment, Y::Outcome, doT::Intervention)          # :97-136
+    n = size(Y, 1)
+    @assert size(X, 1) == n
+    @assert size(T, 1) == n
+    _likelihood_blocks(nothing, xyLS, tyLS, yNoise, yScale, nothing, X, T, Y, doT)
+end
+
+function likelihoodDistribution(uyLS::Nothing, xyLS::Nothing, tyLS::Float64, yNoise::Float64, yScale::Float64,
+                                U::Nothing, X::Nothing, T::Treatment, Y::Outcome, doT::Intervention)             # :139-174
+    @assert size(T, 1) == size(Y, 1)
+    _likelihood_blocks(nothing, nothing, tyLS, yNoise, yScale, nothing, nothing, T, Y, doT)
+end
+
+# ---- src/estimation.jl --------------------------------------------------------------------------------------------
+function conditionalITE(uyLS::Union{Vector{Float64},Nothing}, xyLS::Union{Array{Float64},Nothing}, tyLS::Float64,
+                        yNoise::Float64, yScale::Float64, U::Union{Confounders,Nothing}, X::Union{Covariates,Nothing},
+                        T::Treatment, Y::Outcome, doT::Intervention)                                              # :36-50
+    n = size(Y, 1)
+    c = GPSLCHip.Ctx(n, X === nothing ? 0 : size(X, 2), U === nothing ? 0 : size(U, 2))
+    GPSLCHip.set_data!(c, X, T, Y)
+    p = GPSLCHip.Pack(U === nothing ? nothing : reshape(GPSLCHip.f64(U), n, :, 1),
+                      uyLS === nothing ? nothing : reshape(copy(uyLS), :, 1),
+                      xyLS === nothing ? nothing : reshape(GPSLCHip.f64(vec(xyLS)), :, 1),
+                      [tyLS], [yNoise], [yScale])
+    M, Cv = GPSLCHip.ite_distributions(c, p, Float64(doT), 0.0)          # CovITE itself: the jitter is ITEDistributions' (:82)
+    GPSLCHip.destroy!(c)
+    M[1, :], Cv[1, :, :]
+end
+
+function conditionalITE(g::GPSLCObject, psindex::Int64, doT::Intervention)                                        # :57-60
+    uyLS, xyLS, tyLS, yNoise, yScale, U = extractParameters(g, psindex)
+    conditionalITE(uyLS, xyLS, tyLS, yNoise, yScale, U, g.X, g.T, g.Y, doT)
+end
+
+function ITEDistributions(g::GPSLCObject, doT::Intervention)                                                       # :66-86
+    GPSLCHip.ite_distributions(ctx(g), posterior_pack(g), Float64(doT), g.hyperparams.predictionCovarianceNoise)
+end
+
+function SATEDistributions(g::GPSLCObject, doT::Intervention)                                                      # :127-140
+    mS, vS, _, _ = GPSLCHip.predict(ctx(g), posterior_pack(g), [Float64(doT)], g.hyperparams.predictionCovarianceNoise)
+    mS[:, 1], vS[:, 1]          # O(N^2) per posterior sample: the N x N covariance is never formed
+end
+
+# ---- src/driver.jl ------------------------------------------------------------------------------------------------
+function sampleITE(g::GPSLCObject, doT::Intervention; samplesPerPosterior::Int64=10)                               # :86-89
+    n, S = getN(g), getNumPosteriorSamples(g)
+    z = randn(n, samplesPerPosterior, S, 1)                               # Julia's global RNG, as Gen.mvnormal would
+    _, _, _, ite = GPSLCHip.predict(ctx(g), posterior_pack(g), [Float64(doT)], g.hyperparams.predictionCovarianceNoise;
+                                    spp=samplesPerPosterior, z=z, want_draws=true)
+    ite[1, :, :]                                                          # n x (S * spp), sample outer / draw inner (:100-107)
+end
+
+function sampleSATE(g::GPSLCObject, doT::Intervention; samplesPerPosterior::Int64=10)                              # :108-111
+    MeanSATEs, VarSATEs = SATEDistributions(g, doT)
+    z = randn(length(MeanSATEs) * samplesPerPosterior)
+    GPSLCHip.sate_samples(MeanSATEs, VarSATEs, samplesPerPosterior; z=z)  # normal(mean, var): variance as sigma (:159)
+end
+
+function summarizeEstimates(samples; savetofile::String="", credible_interval::Float64=0.90)                        # :129-149
+    Mean, lowerBound, upperBound = GPSLCHip.summarize(GPSLCHip.kctx(), Matrix{Float64}(samples), credible_interval)
+    df = DataFrame(Individual=1:size(Mean, 1), Mean=Mean, LowerBound=lowerBound, UpperBound=upperBound)
+    if savetofile != ""
+        CSV.write(savetofile, df)
+        println("Saved mean and 90% credible intervals to " * savetofile)
+    end
+    return df
+end
+
+# ---- src/prediction.jl --------------------------------------------------------------------------------------------
+function predictCounterfactualEffects(g::GPSLCObject, nSamplesPerMixture::Int64; fidelity::Int64=100,
+                                      minDoT=min(g.T...), maxDoT=max(g.T...))                                      # :23-36
+    delta = abs(maxDoT - minDoT)
+    step = delta / fidelity
+    doTrange = minDoT:step:maxDoT                                          # :24-28
+    L, n, S = length(doTrange), getN(g), getNumPosteriorSamples(g)
+    z = randn(n, nSamplesPerMixture, S, L)
+    # one factorisation of A per posterior sample, shared by its L levels; `ite` comes back in the reference's
+    # layout (L x n x S*spp, level index fastest)
+    _, _, _, ite = GPSLCHip.predict(ctx(g), posterior_pack(g), Float64.(collect(doTrange)),
+                                    g.hyperparams.predictionCovarianceNoise; spp=nSamplesPerMixture, z=z, want_draws=true)
+    return ite, doTrange
+end
+
+# ---- src/model_likelihood.jl: the :Y node keeps its address and value type; only the distribution object changes ----
+struct HipYNormal <: Gen.Distribution{Vector{Float64}} end
+const hip_y_normal = HipYNormal()
+
+function Gen.logpdf(::HipYNormal, y::Vector{Float64}, c::GPSLCHip.Ctx, U, X, uyLS, xyLS, tyLS::Float64,
+                    yScale::Float64, yNoise::Float64)
+    # y = the value Gen is scoring (Y_or_null); X = the trace's :X => k => :X values (X_or_null) or nothing
+    GPSLCHip.y_logpdf(c, 1, U, X, y, uyLS, xyLS, [tyLS], [yScale], [yNoise])[1]
+end
+
+function Gen.random(::HipYNormal, c::GPSLCHip.Ctx, U, X, uyLS, xyLS, tyLS::Float64, yScale::Float64, yNoise::Float64)
+    # prior sampling only (generate without a constraint on :Y): chol(Ycov) * randn through the node-draw entry point,
+    # F = [U | X | T] with the data set's treatment column (n <= 640: the sizes the single-launch node kernels cover)
+    Xh, Th, _ = c.data
+    Xuse = X === nothing ? Xh : X
+    cols = Matrix{Float64}[]
+    ls = Float64[]
+    if U !== nothing
+        push!(cols, _mat(U))
+        append!(ls, uyLS)
+    end
+    if Xuse !== nothing
+        push!(cols, _mat(Xuse))
+        append!(ls, vec(xyLS))
+    end
+    push!(cols, _mat(Th))
+    push!(ls, tyLS)
+    F = reduce(hcat, cols)
+    z = randn(c.n)
+    y = GC.@preserve F ls z begin
+        node = GPSLCHip.GPSLCNode(size(F, 2), 0, pointer(F), pointer(ls), yScale, yNoise, pointer(z))
+        GPSLCHip.nodes_draw(c, [node])
+    end
+    y[:, 1]
+end
+Gen.has_output_grad(::HipYNormal) = false
+Gen.has_argument_grads(::HipYNormal) = ntuple(_ -> false, 9)
+Gen.logpdf_grad(::HipYNormal, y, args...) = ntuple(_ -> nothing, 10)
+# generateYfromUXT (src/model_likelihood.jl:83-91):   Y = @trace(hip_y_normal(c, U, X, uyLS, xyLS, tyLS, yScale, yNoise), :Y)

@@ -153,6 +153,126 @@ def test_world_size_2_real_hip_path_on_one_device(tmp_path, S):
         assert not np.array_equal(ms64, ms) and np.allclose(ms64, ms, rtol=1e-5)
 
 
+# ---- gather policies for the large outputs ("gather to rank 0 (or all-gather) ... optionally meanITE and draws")
+
+def _oracle_compute_with_draws(g_local, doTs, spp, z_local):
+    """CPU stand-in with draws: (ms, vs, mi, draws (L, n, S_r*spp)) — the reference's sampleITE per level
+    (src/estimation.jl:95-109: mean + chol(CovITE + jitter) z, sample outer / draw inner)."""
+    ms, vs, mi = _oracle_compute_with_mean(g_local, doTs)
+    S, n, L = g_local.getNumPosteriorSamples(), g_local.getN(), len(doTs)
+    dr = np.zeros((L, n, S * spp))
+    for s in range(S):
+        p = orc.PosteriorSample(None if g_local.uyLS is None else g_local.uyLS[:, s],
+                                None if g_local.xyLS is None else g_local.xyLS[:, s],
+                                float(g_local.tyLS[s]), float(g_local.yNoise[s]), float(g_local.yScale[s]),
+                                None if g_local.U is None else g_local.U[:, :, s])
+        for l, d in enumerate(doTs):
+            M, Cv = orc.ite_distributions([p], g_local.X, g_local.T, g_local.Y, float(d), pred_noise=1e-6)
+            Lc = np.linalg.cholesky(Cv[0])
+            for k in range(spp):
+                dr[l, :, s * spp + k] = M[0] + Lc @ z_local[:, k, s, l]
+    return ms, vs, mi, dr
+
+
+def _worker_modes(rank, world, port, S, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import causalgpslc_jl_amd as gp
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = cases.make_case(12, "UX", False, S=S, seed=8)
+    g = cases.gpslc_object(gp, c)
+    doTs, spp = np.array([0.2, 0.7]), 3
+    z = np.random.default_rng(0).standard_normal((12, spp, S, 2))
+    out = {}
+    r = gp.predict_sharded_full(g, doTs, compute=_oracle_compute_with_draws, sate="root", mean_ite="root",
+                                draws="root", spp=spp, z=z, root=1)
+    out["root_has"] = np.array([r.meanSATE is not None, r.meanITE is not None, r.draws is not None])
+    if rank == 1:
+        out.update(ms=r.meanSATE, vs=r.varSATE, mi=r.meanITE.numpy(), dr=r.draws.numpy())
+    r = gp.predict_sharded_full(g, doTs, compute=_oracle_compute_with_draws, sate="all", mean_ite="local",
+                                draws="local", spp=spp, z=z)
+    out.update(l_ms=r.meanSATE, l_mi=r.meanITE.numpy(), l_dr=r.draws.numpy(), l_rng=np.array([r.s0, r.s1]))
+    r = gp.predict_sharded_full(g, doTs, compute=_oracle_compute_with_draws, sate="none", mean_ite="none",
+                                draws="all", spp=spp, z=z, to_host=True)
+    out.update(a_dr=r.draws, n_ms=r.meanSATE, none_mi=np.array([r.meanITE is None]))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S", [5, 1])
+def test_world_size_2_gloo_gather_policies_root_local_all(tmp_path, S):
+    """MeanITE and draws: "root" delivers the whole tensor to the root rank ONLY (one gather), "local" leaves each rank
+    its own block, "all" is the explicit all_gather; SATE "root" / "none" likewise.  Uneven and empty shards."""
+    import torch.multiprocessing as mp
+    import causalgpslc_jl_amd as gp
+    port = 35500 + (os.getpid() + S) % 2000
+    mp.spawn(_worker_modes, args=(2, port, S, str(tmp_path)), nprocs=2, join=True)
+    c = cases.make_case(12, "UX", False, S=S, seed=8)
+    g = cases.gpslc_object(gp, c)
+    doTs, spp = np.array([0.2, 0.7]), 3
+    z = np.random.default_rng(0).standard_normal((12, spp, S, 2))
+    ms, vs, mi, dr = _oracle_compute_with_draws(g, doTs, spp, z)
+    d0 = np.load(os.path.join(tmp_path, "rank0.npz"))
+    d1 = np.load(os.path.join(tmp_path, "rank1.npz"))
+    assert not d0["root_has"].any() and d1["root_has"].all()          # root = 1: rank 0 received nothing
+    for k, x in zip(("ms", "vs", "mi", "dr"), (ms, vs, mi, dr)):
+        assert np.array_equal(d1[k], x), k
+    for d in (d0, d1):
+        a, b = d["l_rng"]
+        assert np.array_equal(d["l_ms"], ms)                           # SATE "all": every rank
+        assert np.array_equal(d["l_mi"], mi[:, a:b, :]) and np.array_equal(d["l_dr"], dr[:, :, a * spp:b * spp])
+        assert np.array_equal(d["a_dr"], dr) and d["none_mi"][0]
+        assert np.array_equal(d["n_ms"], ms[a:b])                      # SATE "none": the rank's own block
+
+
+def _worker_hip_modes(rank, world, port, S, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    import torch.distributed as dist
+    import causalgpslc_jl_amd as gp
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.random.default_rng(1).standard_normal((150, 2, S, 2))
+    r = gp.predict_sharded_pack(os.path.join(out_dir, "g.pk"), np.array([0.3, 0.6]), mean_ite="root", draws="root",
+                                spp=2, z=z, to_host=True)
+    out = {"has": np.array([r.meanITE is not None, r.draws is not None]), "ms": r.meanSATE, "vs": r.varSATE}
+    if rank == 0:
+        out.update(mi=r.meanITE, dr=r.draws)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [5, 1])
+def test_world_size_2_real_hip_path_root_gather_of_mean_ite_and_draws(tmp_path, S):
+    """The real HIP entry point under a 2-rank group (both on device 0): MeanITE and the draw tensor are gathered to
+    rank 0 only and equal the single-process prediction with the same normals bit for bit."""
+    import torch.multiprocessing as mp
+    import causalgpslc_jl_amd as gp
+    c = cases.make_case(150, "UX", False, S=S, seed=6)
+    g = cases.gpslc_object(gp, c)
+    gp.saveGPSLCObject(g, str(tmp_path / "g.pk"))
+    port = 37500 + (os.getpid() + S) % 2000
+    mp.spawn(_worker_hip_modes, args=(2, port, S, str(tmp_path)), nprocs=2, join=True)
+    z = np.random.default_rng(1).standard_normal((150, 2, S, 2))
+    ms, vs, mi, dr = gp.predict(g, np.array([0.3, 0.6]), want_mean_ite=True, spp=2, z=z, want_draws=True)
+    d0 = np.load(os.path.join(tmp_path, "rank0.npz"))
+    d1 = np.load(os.path.join(tmp_path, "rank1.npz"))
+    assert d0["has"].all() and not d1["has"].any()
+    assert np.array_equal(d0["mi"], mi) and np.array_equal(d0["dr"], dr)
+    for d in (d0, d1):
+        assert np.array_equal(d["ms"], ms) and np.array_equal(d["vs"], vs)
+
+
 def test_shard_range_partitions_exactly():
     import causalgpslc_jl_amd as gp
     for S in (0, 1, 7, 8, 8192):
