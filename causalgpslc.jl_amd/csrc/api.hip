@@ -1439,18 +1439,24 @@ int gpslc_nodes_logpdf(gpslc_ctx* c, int32_t count, const gpslc_node* nodes, dou
             }
             return small_nodes_logpdf(c, count, hn.data(), logpdf);
         }
-        // larger n: one pass of the general tiled path per node (their feature counts differ)
-        int first = 0;
-        std::vector<int32_t> infos((size_t)count, 0);
+        // larger n: ONE batched pass of the general tiled path over all nodes (S = count parameter sets with per-set
+        // feature blocks and per-set targets).  Nodes with fewer than nF_max feature columns are padded with zero
+        // columns of lengthscale 1: a padding column adds (0 * 1 - 0 * 1)^2 = +0.0 to every squared distance, so a
+        // node's Gram matrix — and its score — is bit-identical to the one its own feature count would give.
+        const size_t n = (size_t)c->n;
+        std::vector<double> Fp(n * (size_t)nF_max * count, 0.0), lsp((size_t)std::max(nF_max, 1) * count, 1.0);
+        std::vector<double> sc((size_t)count), no((size_t)count), tg(n * (size_t)count);
         for (int i = 0; i < count; ++i) {
             const gpslc_node& q = nodes[i];
-            const int st = gp_logpdf_general(c, 1, q.nF, q.F, 1, q.ls, &q.scale, &q.noise, q.target, 1, logpdf + i);
-            if (st < 0) return st;
-            infos[i] = st;
-            if (st > 0 && first == 0) first = st;
+            if (q.nF > 0) {
+                memcpy(Fp.data() + (size_t)i * n * nF_max, q.F, n * (size_t)q.nF * sizeof(double));
+                memcpy(lsp.data() + (size_t)i * nF_max, q.ls, (size_t)q.nF * sizeof(double));
+            }
+            sc[i] = q.scale; no[i] = q.noise;
+            memcpy(tg.data() + (size_t)i * n, q.target, n * sizeof(double));
         }
-        c->last_info = infos;
-        return first;
+        return gp_logpdf_general(c, count, nF_max, nF_max ? Fp.data() : nullptr, 0, nF_max ? lsp.data() : nullptr,
+                                 sc.data(), no.data(), tg.data(), 0, logpdf);
     });
 }
 

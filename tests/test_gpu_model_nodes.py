@@ -127,3 +127,39 @@ def test_near_singular_matrix_tiled_path_matches_lapack(gp):
     z = np.linalg.solve(Lc, x)
     ref = -0.5 * (n * np.log(2 * np.pi) + 2 * np.sum(np.log(np.diag(Lc))) + z @ z)
     assert abs(out[0] - ref) <= 1e-6 * abs(ref), (out[0], ref)
+
+
+@pytest.mark.parametrize("n", [700, 2048])
+def test_fused_model_score_beyond_the_single_workgroup_kernels_is_one_batched_pass(gp, n):
+    """gpslc_nodes_logpdf for n > 640: the nodes of one Gen `update` (src/model.jl:11-27: two :X => k => :X nodes with
+    F = U, the :T node with F = [U | X], the :Y node with F = [U | X | T]) have DIFFERENT feature counts and are scored
+    by ONE batched pass of the tiled path (zero-padded feature columns of lengthscale 1).  Against the oracle's
+    restatement of the Gen node scores, and bit-identical to scoring each node on its own."""
+    rng = np.random.default_rng(n)
+    nU, nX = 2, 3
+    U = rng.standard_normal((n, nU))
+    X = rng.standard_normal((n, nX))
+    T = rng.standard_normal(n)
+    Y = np.sin(T) + 0.5 * X[:, 0] + 0.3 * rng.standard_normal(n)
+    uxLS = rng.uniform(0.8, 2.0, (nX, nU))
+    xScale, xNoise = rng.uniform(0.5, 2.0, nX), rng.uniform(0.3, 1.0, nX)
+    utLS, xtLS = rng.uniform(0.8, 2.0, nU), rng.uniform(0.8, 2.0, nX)
+    uyLS, xyLS, tyLS = rng.uniform(0.8, 2.0, nU), rng.uniform(0.8, 2.0, nX), 1.3
+    tScale, tNoise, yScale, yNoise = 1.2, 0.6, 0.9, 0.5
+    nodes = [(U, uxLS[k], xScale[k], xNoise[k], X[:, k]) for k in range(2)]
+    nodes.append((np.hstack([U, X]), np.concatenate([utLS, xtLS]), tScale, tNoise, T))
+    nodes.append((np.hstack([U, X, T[:, None]]), np.concatenate([uyLS, xyLS, [tyLS]]), yScale, yNoise, Y))
+    ctx = gp.Context(n, 0, 0)
+    out = gp.nodesLogpdf(nodes, ctx)
+    ref = [orc.x_node_logpdf(U, uxLS[k], xScale[k], xNoise[k], X[:, k]) for k in range(2)]
+    ref.append(orc.t_node_logpdf(U, X, utLS, xtLS, tScale, tNoise, T))
+    ref.append(orc.y_logpdf(uyLS, xyLS, tyLS, yScale, yNoise, U, X, T, Y))
+    assert np.allclose(out, ref, rtol=1e-11, atol=1e-9), (out, ref)
+    assert not ctx.last_info(len(nodes)).any()
+    for i, q in enumerate(nodes):          # padding columns add exact zeros: same bits as the node's own pass
+        assert gp.nodesLogpdf([q], ctx)[0] == out[i], i
+    # a failing node reports its pivot and leaves the others' scores alone
+    bad = list(nodes)
+    bad[1] = (U, uxLS[1], xScale[1], -5.0, X[:, 1])
+    got = gp.nodesLogpdf(bad, ctx, fail_value=-np.inf)
+    assert got[1] == -np.inf and got[0] == out[0] and got[2] == out[2] and got[3] == out[3]
