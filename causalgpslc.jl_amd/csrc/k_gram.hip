@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = FT > 0 ? FT : g.nU + g.nX;
     double* red = sm;                    // [4][128][2] cross-wave row-sum staging
-    RT* fr = reinterpret_cast<RT*>(red + 4 * GP_TS * 2);   // [F][128] row-block features / LS
+    double* etab = red + 4 * GP_TS * 2;  // [32] 2^(j/32) for the table-driven exp (gp_math.h)
+    RT* fr = reinterpret_cast<RT*>(etab + GP_EXP_TAB_DOUBLES);   // [F][128] row-block features / LS
     RT* fc = fr + F * GP_TS;             // [F][128] column-block features / LS
     RT* tr = fc + F * GP_TS;             // [128] T of row block
     RT* tc = tr + GP_TS;                 // [128]
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
         tr[tid] = (RT)((gi0 + tid < n) ? g.T[gi0 + tid] : 0.0);
         tc[tid] = (RT)((gj0 + tid < n) ? g.T[gj0 + tid] : 0.0);
     }
+    gp_exp_tab_stage(etab, tid);
     __syncthreads();
 #ifdef GPSLC_DIAG
     const unsigned long long dt1 = g.dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     const double yn = g.p.yNoise[s];
     const double tl = g.p.tyLS[s];
     const RT wt = (RT)(1.0 / (tl * tl));
-    const RT ew = RbfMath<RT>::exp_neg(-wt);     // e_ij for |T_i - T_j| = 1 (binary treatments)
+    const RT ew = RbfMath<RT>::exp_neg_t(-wt, etab);     // e_ij for |T_i - T_j| = 1 (binary treatments)
     const int ty = tid & 15, tx = tid >> 4;
 
     RT tra[8];
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
                 const int rp = ty + 16 * p;
                 const int gi = gi0 + rp;
                 const RT dt = tra[p] - tcq;
-                const RT Bq = (RT)ys * RbfMath<RT>::exp_neg(-lux[p]);
-                const RT Eq = BIN ? (dt == (RT)0 ? (RT)1 : ew) : RbfMath<RT>::exp_neg(-((dt * dt) * wt));
+                const RT Bq = (RT)ys * RbfMath<RT>::exp_neg_t(-lux[p], etab);
+                const RT Eq = BIN ? (dt == (RT)0 ? (RT)1 : ew) : RbfMath<RT>::exp_neg_t(-((dt * dt) * wt), etab);
                 double Bv, Kv, Av;
                 if (FAST) {
                     Bv = (double)Bq; Kv = (double)(Bq * Eq); Av = Kv;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     }
 }
 
-#define GRAM_LDS_BYTES(F, RTS) (4 * GP_TS * 2 * 8 + (2 * (F) * GP_TS + 2 * GP_TS) * (RTS))
+#define GRAM_LDS_BYTES(F, RTS) (4 * GP_TS * 2 * 8 + GP_EXP_TAB_DOUBLES * 8 + (2 * (F) * GP_TS + 2 * GP_TS) * (RTS))
 
 template <typename RT, int BIN, int FT>
 static void launch_gram_t(const GramArgs& g, int nbatch, hipStream_t st) {

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     // rows of the same thread (the LDS pipe, not the fp64 VALU, bounded the RB = 1 form)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = a.nU + a.nX;
-    double* al = sm;                       // [128]
+    double* etab = sm;                     // [32] 2^(j/32): table-driven exp (gp_math.h)
+    double* al = etab + GP_EXP_TAB_DOUBLES;   // [128]
     double* rl = al + GP_TS;               // [LCT][128]
     double* red = rl + LCT * GP_TS;        // [RB][128][LCT]
     RT* fc = reinterpret_cast<RT*>(red + RB * GP_TS * LCT);   // [FREG][128] column features / LS (zero rows beyond F)
@@ -123,7 +124,9 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     const double tl = a.p.tyLS[s];
     const double wt = 1.0 / (tl * tl);
     const RT wtq = (RT)wt;
-    const RT ewq = RbfMath<RT>::exp_neg(-wtq);
+    gp_exp_tab_stage(etab, tid);
+    __syncthreads();
+    const RT ewq = RbfMath<RT>::exp_neg_t(-wtq, etab);
     const double* alpha = a.alpha + b * Np;
 
     for (int l0 = 0; l0 < a.L; l0 += LCT) {
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
                 double v = 0.0;
                 if (ll < nl && g < n) {
                     const RT dt = (RT)a.T[g] - (RT)a.doT[l0 + ll];
-                    v = (double)RbfMath<RT>::exp_neg(-((dt * dt) * wtq));
+                    v = (double)RbfMath<RT>::exp_neg_t(-((dt * dt) * wtq), etab);
                 }
                 rl[idx] = v;
             }
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
                         lux = fma(d, d, lux);
                     }
                     const RT dt = tri[q] - tc;
-                    const double Bv = (double)((RT)ys * RbfMath<RT>::exp_neg(-lux));
-                    const double Ev = (double)(BIN ? (dt == (RT)0 ? (RT)1 : ewq) : RbfMath<RT>::exp_neg(-((dt * dt) * wtq)));
+                    const double Bv = (double)((RT)ys * RbfMath<RT>::exp_neg_t(-lux, etab));
+                    const double Ev = (double)(BIN ? (dt == (RT)0 ? (RT)1 : ewq) : RbfMath<RT>::exp_neg_t(-((dt * dt) * wtq), etab));
                     const double ba = Bv * alc;
 #pragma unroll
                     for (int ll = 0; ll < LCT; ++ll) acc[q][ll] = fma(ba, rlc[ll] - Ev, acc[q][ll]);
@@ -227,7 +230,8 @@ template <int FREG, int BIN>   // FREG > 0: this lane's two rows' features live 
 __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = a.nU + a.nX;
-    double* fr = sm;                         // [F][128] row features / LS
+    double* etab = sm;                       // [32] 2^(j/32): table-driven exp (gp_math.h)
+    double* fr = etab + GP_EXP_TAB_DOUBLES;  // [F][128] row features / LS
     const int FSL = FREG > F ? FREG : F;
     double* fc = fr + F * GP_TS;             // [max(F, FREG)][IM_CC] column features / LS
     double* trs = fc + FSL * IM_CC;          // [128]
@@ -259,9 +263,10 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
     const double tl = a.p.tyLS[s];
     const double wt = 1.0 / (tl * tl);
     const double* alpha = a.alpha + b * Np;
-    const double ew = gp_exp_neg(-wt);
+    gp_exp_tab_stage(etab, tid);
     const int r0 = 32 * wave + li;           // this lane's rows: r0 and r0 + 16
     __syncthreads();
+    const double ew = gp_exp_neg_tab(-wt, etab);
     double af0[FREG > 0 ? FREG : 1], af1[FREG > 0 ? FREG : 1];
     if (FREG > 0) {
 #pragma unroll
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
                 double v = 0.0;
                 if (ll < nl && g < n) {
                     const double dt = a.T[g] - a.doT[l0 + ll];
-                    v = gp_exp_neg(-((dt * dt) * wt)) * alpha[g];
+                    v = gp_exp_neg_tab(-((dt * dt) * wt), etab) * alpha[g];
                 }
                 R[cc * IM_RLD + ll] = v;
             }
@@ -329,9 +334,9 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
                 }
                 const double tc = tcs[cc];
                 const double dt0 = t0 - tc, dt1 = t1 - tc;
-                const double B0 = ys * gp_exp_neg(-lux0), B1 = ys * gp_exp_neg(-lux1);
-                const double E0 = BIN ? (dt0 == 0.0 ? 1.0 : ew) : gp_exp_neg(-((dt0 * dt0) * wt));
-                const double E1 = BIN ? (dt1 == 0.0 ? 1.0 : ew) : gp_exp_neg(-((dt1 * dt1) * wt));
+                const double B0 = ys * gp_exp_neg_tab(-lux0, etab), B1 = ys * gp_exp_neg_tab(-lux1, etab);
+                const double E0 = BIN ? (dt0 == 0.0 ? 1.0 : ew) : gp_exp_neg_tab(-((dt0 * dt0) * wt), etab);
+                const double E1 = BIN ? (dt1 == 0.0 ? 1.0 : ew) : gp_exp_neg_tab(-((dt1 * dt1) * wt), etab);
                 const double K0 = B0 * E0, K1 = B1 * E1;
                 const double av = (li == 0) ? al[cc] : 0.0;       // alpha as a one-column right operand
                 const double* Rrow = R + cc * IM_RLD + li;
@@ -370,9 +375,9 @@ template <int FREG, int BIN>
 static void launch_ite_mean_mfma_tb(const IteMeanArgs& a, int nbatch, hipStream_t st) {
     const int F = a.nU + a.nX;
     const int FS = FREG > F ? FREG : F;
-    const int bytes = (F * GP_TS + FS * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8;
+    const int bytes = (GP_EXP_TAB_DOUBLES + F * GP_TS + FS * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8;
     static DeviceOnce attr_set;
-    lds_opt_in(attr_set, (const void*)ite_mean_mfma_kernel<FREG, BIN>, (MAXF * GP_TS + MAXF * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8);
+    lds_opt_in(attr_set, (const void*)ite_mean_mfma_kernel<FREG, BIN>, (GP_EXP_TAB_DOUBLES + MAXF * GP_TS + MAXF * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8);
     hipLaunchKernelGGL((ite_mean_mfma_kernel<FREG, BIN>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
 }
 template <int FREG>
@@ -393,7 +398,7 @@ static void launch_ite_mean_mfma(const IteMeanArgs& a, int nbatch, hipStream_t s
 template <int FREG, int LCT, typename RT, int BIN>
 static void launch_ite_mean_tb(const IteMeanArgs& a, int nbatch, hipStream_t st) {
     constexpr int RB = 1;     // row blocks per workgroup (2 measured slower: occupancy)
-    const int bytes = (GP_TS + (1 + RB) * LCT * GP_TS) * 8 + (FREG * GP_TS + GP_TS) * (int)sizeof(RT);
+    const int bytes = (GP_EXP_TAB_DOUBLES + GP_TS + (1 + RB) * LCT * GP_TS) * 8 + (FREG * GP_TS + GP_TS) * (int)sizeof(RT);
     static DeviceOnce attr_set;
     lds_opt_in(attr_set, (const void*)ite_mean_kernel<FREG, LCT, RT, RB, BIN>, bytes);
     hipLaunchKernelGGL((ite_mean_kernel<FREG, LCT, RT, RB, BIN>), dim3((a.nt + RB - 1) / RB, nbatch), dim3(256), bytes, st, a);
