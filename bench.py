@@ -16,7 +16,7 @@ device pointers; torch only provides device memory and the process group).  Post
 with no data-path collective; one all_gather of the (S x L) SATE arrays closes each step (weak scaling).
 
 The JSON line carries
-  roofline      the dominant kernel (tile_gemm_nt_kernel<1, 0, 0>, the f64-MFMA tile update): algorithmic flop
+  roofline      the dominant kernel (tile_gemm_nt_kernel<1, 0>, the f64-MFMA tile update): algorithmic flop
                 (textbook count: diagonal tiles half, augmented rows by their live rows) / HIP-event time of every
                 launch inside the timed region, against the fp64 matrix peak (78.6 TFLOP/s, AMD spec; the guides
                 list no f64 MFMA rate — DESIGN.md §4 has the measured micro-benchmark: 76 TFLOP/s register-only);
@@ -492,9 +492,9 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    launches, kms, kflop = ctx.profile_get(0)      # tile_gemm_nt_kernel<1, 0, 0>: the dominant kernel
+    launches, kms, kflop = ctx.profile_get(0)      # tile_gemm_nt_kernel<1, 0>: the dominant kernel
     launches1, kms1, kflop1 = ctx.profile_get(1)   # tile_fused_strip_kernel: in-panel column update fused with the panel solve
-    kname = "tile_gemm_nt_kernel<1, 0, 0> (f64 MFMA tile update: trailing updates of the blocked Cholesky)"
+    kname = "tile_gemm_nt_kernel<1, 0> (f64 MFMA tile update: trailing updates of the blocked Cholesky)"
     kname1 = "tile_fused_strip_kernel<8> (f64 MFMA tile update: in-panel column update fused with the panel solve)"
 
     # ---- BASELINE configs[3]: the same posterior samples x 64 intervention levels (the sweep of

@@ -32,6 +32,8 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) char* gchar_p;     // global address space kept through opaque (asm) copies
+typedef const __attribute__((address_space(1))) d2* gd2_p;
 
 // measurement-only paths (in-kernel stamps, timing-only variants) exist in the -DGPSLC_DIAG build only
 #ifdef GPSLC_DIAG
@@ -46,6 +48,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define LROW 144                      // padded k-row (doubles)
 #define OPER_LDS (KS * LROW)          // doubles per operand per stage
 #define GEMM_LDS_BYTES (2 * 2 * OPER_LDS * 8)
+#ifndef SADDR_LOADS
+#define SADDR_LOADS 0
+#endif
 #ifndef STRIP_NT
 #define STRIP_NT 2       // A slabs and C tiles are streamed once per launch: non-temporal, so that they do not displace the shared
                          // B(k, kk) slabs and inv(L_kk) in L2 (measured: fused kernel +1.8 %, profiles/r03_ab_experiments.md)
@@ -78,16 +83,7 @@ __device__ __forceinline__ d4 mfma_step(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, NEG);
 }
 
-// FUSE = 1 (ACC = 1 only): the in-panel column update AND the panel product of the same tile in one item,
-//     X = C(i,k) - sum_kk A(i,kk) B(k,kk)^T   (the K loop, X stays in the accumulators)
-//     L(i,k) = X * inv(L_kk)^T                  (second phase, GemmArgs::F holds the inverted diagonal blocks)
-// so the column tiles make one HBM round trip instead of two (the separate panel product is HBM bound: 127 MB per
-// sample).  The accumulator layout (row = lane&15, col = (lane>>4) + 4v) IS the k-layout of an MFMA operand, so
-// X feeds the second product straight from the registers; only the 64 x 64 block X(:, 0:64) * W(64:128, 0:64)^T
-// crosses from the left-hand waves to the right-hand ones, through the (idle) staging LDS.  inv(L_kk) is lower
-// triangular: sub-block products above its diagonal are skipped.  Summation order per output element = ascending
-// column of X, as in the separate panel kernel.
-template <int ACC, int DIAG, int FUSE = 0>
+template <int ACC, int DIAG>
 __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
@@ -140,12 +136,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         // sym == 2: the full-size diagonal tiles of this launch belong to tile_syrk_diag_kernel
         if (g.sym >= 2 && ti == tj && !(g.short_rows > 0 && ti >= g.short_row0)) break;
         // sym == 3: the augmented-row tiles of the columns that have a full-size diagonal tile ride with it
-        bool no_update = false;     // FUSE: the augmented tile was already updated (it rode with the diagonal item);
-                                    // it only takes the panel product here
-        if (g.sym == 3 && g.short_rows > 0 && ti >= g.short_row0 && tj < g.short_row0) {
-            if (!FUSE) break;
-            no_update = true;
-        }
+        if (g.sym == 3 && g.short_rows > 0 && ti >= g.short_row0 && tj < g.short_row0) break;
         if (GP_DIAG_SKIP(g) == 3 && g.short_rows > 0 && ti >= g.short_row0) break;   // timing-only: price of the short tiles
 
         double* __restrict__ Ct = tref_tile(g.C, b, ti, tj);
@@ -195,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                 for (int n = 0; n < 4; ++n) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
         }
 
-        if (nslab > 0 && !no_update) {
+        if (nslab > 0) {
             // staging: 16 KiB per operand per slab = 1024 16-byte chunks, 4 per thread, contiguous in HBM
             d2 ra[4], rb[4];     // staging set A
             d2 ra2[4], rb2[4];   // staging set B: loads run two slabs ahead of the MFMAs
@@ -207,11 +198,27 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                 // panel product of a short (augmented-row) tile: the chunks of A below its live rows are never
                 // used — point them at chunk 0 of their k-column's line instead of streaming zeros
                 const int ao = (!ACC && ((tid & 63) * 2) >= 16 * prow) ? (tid & ~63) * 2 : tid * 2;
+#if SADDR_LOADS
+                // the four 4 KiB quarters of a slab through four UNIFORM bases (scalar adds) + one 32-bit lane offset: the
+                // saddr form of global_load — no 64-bit VALU address arithmetic between the MFMAs (a VALU instruction
+                // there costs ~5.6 pipe clocks, profiles/r03_ab_experiments.md §5)
+                const unsigned va = (unsigned)ao * 8u, vb = (unsigned)tid * 16u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    gchar_p qa = (gchar_p)(reinterpret_cast<const char*>(pa)) + 4096 * u;
+                    gchar_p qb = (gchar_p)(reinterpret_cast<const char*>(pb)) + 4096 * u;
+                    unsigned va_ = va, vb_ = vb;
+                    asm volatile("" : "+s"(qa), "+s"(qb), "+v"(va_), "+v"(vb_));
+                    xa[u] = *(gd2_p)(qa + va_);
+                    xb[u] = *(gd2_p)(qb + vb_);
+                }
+#else
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     xa[u] = *reinterpret_cast<const d2*>(pa + ao + 512 * u);
                     xb[u] = *reinterpret_cast<const d2*>(pb + (tid + 256 * u) * 2);
                 }
+#endif
             };
             auto lstore = [&](int buf, const d2 (&xa)[4], const d2 (&xb)[4]) {
 #pragma unroll
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                 const int nlo = ACC ? 0 : min(4, max(0, (s & 7) - 4 * wc));
                 // trailing updates (no second phase, registers to spare): the fragments of k-step ks + 1 are read from LDS
                 // before the 16 MFMAs of k-step ks are issued, so that a wave never starts a k-step with an LDS round trip
-                constexpr bool PIPE = ACC && !FUSE && DIAG == 0;
+                constexpr bool PIPE = ACC && DIAG == 0;
                 double afn[4], bfn[4];
                 if (PIPE) {
 #pragma unroll
@@ -327,85 +334,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         }
         if (GP_DBG_ON(g)) st2 = __builtin_amdgcn_s_memtime();
 
-        if (FUSE) {
-            const int li = lane & 15, lg = lane >> 4;
-            const double* __restrict__ Wl = tref_tile(g.F, b, 0, g.fk) + (lg * GP_TS + li);   // W(c, c') at c'*128 + c
-            double* lP = smem;                                   // [wr][nc][m][v][64 lanes], 64 KiB
-            if (nslab == 0 || no_update) __syncthreads();        // (the K loop ends with a barrier otherwise)
-            // The fragments of W = inv(L_kk) come from L2 (the tile is shared by every item of the launch).  Loaded right
-            // before their four MFMAs, every group waited a full L2 round trip (in-kernel stamps: 95 k clocks of second
-            // phase per item against 37 k of MFMA time): they run WD groups (WD x 256 MFMA clocks) ahead instead.
-            constexpr int WD = 4;
-            if (wc == 0) {
-                // X(:, 0:64) * W(64:128, 0:64)^T for the right-hand waves; group q = 16 nc + 4 n + v
-                double wn[WD];
-#pragma unroll
-                for (int q = 0; q < WD; ++q) wn[q] = Wl[(16 * ((q >> 2) & 3) + 4 * (q & 3)) * GP_TS + 64 + 16 * (q >> 4)];
-#pragma unroll
-                for (int nc = 0; nc < 4; ++nc) {
-                    d4 st[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) st[m] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int q = 16 * nc + 4 * n + v, q1 = q + WD;
-                            const double w = wn[q % WD];
-                            if (q1 < 64) wn[q % WD] = Wl[(16 * ((q1 >> 2) & 3) + 4 * (q1 & 3)) * GP_TS + 64 + 16 * (q1 >> 4)];
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) st[m] = mfma_step<0>(w, acc[m][n][v], st[m]);
-                        }
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) lP[((((wr * 4 + nc) * 4 + m) * 4 + v) << 6) + lane] = st[m][v];
-                }
-            }
-            __syncthreads();
-            double* __restrict__ Co = Ct + ((wc * 64 + lg) * GP_TS + wr * 64 + li);
-            const double* __restrict__ Wq = Wl + (64 * wc) * GP_TS + 64 * wc;     // the wave's diagonal quadrant of W
-            double wq[WD];
-#pragma unroll
-            for (int t = 0; t < WD; ++t) {
-                int c1 = 0, r1 = t >> 2;
-                while (r1 > c1) { r1 -= c1 + 1; ++c1; }
-                wq[t] = Wq[(16 * r1 + 4 * (t & 3)) * GP_TS + 16 * c1];
-            }
-#pragma unroll
-            for (int nc = 0; nc < 4; ++nc) {
-                d4 st[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if (wc == 0) st[m] = (d4){0.0, 0.0, 0.0, 0.0};
-                    else {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) st[m][v] = lP[((((wr * 4 + nc) * 4 + m) * 4 + v) << 6) + lane];
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    if (n <= nc) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int t = 4 * (nc * (nc + 1) / 2 + n) + v, t1 = t + WD;     // 40 live groups in the order of use
-                            const double w = wq[t % WD];
-                            if (t1 < 40) {
-                                int c1 = 0, r1 = t1 >> 2;
-                                while (r1 > c1) { r1 -= c1 + 1; ++c1; }
-                                wq[t % WD] = Wq[(16 * r1 + 4 * (t1 & 3)) * GP_TS + 16 * c1];
-                            }
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) st[m] = mfma_step<0>(w, acc[m][n][v], st[m]);
-                        }
-                    }
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) Co[(16 * nc + 4 * v) * GP_TS + 16 * m] = st[m][v];
-            }
-            __syncthreads();     // lP is the staging area of the next item
-        } else {
+        {
         // recompute the store addresses from one opaque offset instead of keeping the 64 preload
         // addresses alive (and spilled) across the K loop
         if (!ACC) {
@@ -578,6 +507,22 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
 #else
                 const double* pb = tref_tile(g.B, b, tj, kk) + so;
 #endif
+#if SADDR_LOADS
+                const unsigned vo = (unsigned)tid * 16u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    gchar_p qa = (gchar_p)(reinterpret_cast<const char*>(pa)) + 4096 * u;
+                    gchar_p qb = (gchar_p)(reinterpret_cast<const char*>(pb)) + 4096 * u;
+                    unsigned vo_ = vo;
+                    asm volatile("" : "+s"(qa), "+s"(qb), "+v"(vo_));
+#if STRIP_NT >= 1
+                    xa[u] = __builtin_nontemporal_load((gd2_p)(qa + vo_));
+#else
+                    xa[u] = *(gd2_p)(qa + vo_);
+#endif
+                    xb[u] = *(gd2_p)(qb + vo_);
+                }
+#else
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
 #if STRIP_NT >= 1
@@ -587,6 +532,7 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
 #endif
                     xb[u] = *reinterpret_cast<const d2*>(pb + (tid + 256 * u) * 2);
                 }
+#endif
             };
             auto lstore = [&](int buf, const d2 (&xa)[4], const d2 (&xb)[4]) {
 #pragma unroll
@@ -929,11 +875,11 @@ void launch_syrk_diag(const GemmArgs& g, int carry_aug, hipStream_t st) {
     else launch_syrk_diag_t<2>(g, grid, st);
 }
 
-template <int ACC, int DIAG, int FUSE = 0>
+template <int ACC, int DIAG>
 static void launch_one(const GemmArgs& g, unsigned grid, hipStream_t st) {
     static DeviceOnce once;
-    lds_opt_in(once, (const void*)tile_gemm_nt_kernel<ACC, DIAG, FUSE>, GEMM_LDS_BYTES);
-    hipLaunchKernelGGL((tile_gemm_nt_kernel<ACC, DIAG, FUSE>), dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
+    lds_opt_in(once, (const void*)tile_gemm_nt_kernel<ACC, DIAG>, GEMM_LDS_BYTES);
+    hipLaunchKernelGGL((tile_gemm_nt_kernel<ACC, DIAG>), dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
 }
 
 void launch_tile_gemm(const GemmArgs& g, hipStream_t st) {
@@ -957,14 +903,9 @@ void launch_tile_gemm(const GemmArgs& g, hipStream_t st) {
     }
 #endif
     if (g.fuse && g.accumulate) {
-        static const int strip = diag_env("GPSLC_FUSE_STRIP", 1);
-        if (strip) {
-            static DeviceOnce once;
-            lds_opt_in(once, (const void*)tile_fused_strip_kernel<FUSE_WD>, GEMM_LDS_BYTES);
-            hipLaunchKernelGGL((tile_fused_strip_kernel<FUSE_WD>), dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
-        } else {
-            launch_one<1, 0, 1>(g, grid, st);
-        }
+        static DeviceOnce once;
+        lds_opt_in(once, (const void*)tile_fused_strip_kernel<FUSE_WD>, GEMM_LDS_BYTES);
+        hipLaunchKernelGGL((tile_fused_strip_kernel<FUSE_WD>), dim3(grid), dim3(256), GEMM_LDS_BYTES, st, g);
     } else {
         if (g.accumulate) launch_one<1, 0>(g, grid, st); else launch_one<0, 0>(g, grid, st);
     }

@@ -123,8 +123,10 @@ int gpslc_gp_logpdf(gpslc_ctx* ctx, int64_t S, int32_t nF, const double* F, int3
  * logpdf[i] = log N(target_i; 0, scale_i * exp.(rbfKernelLog(F_i, F_i, ls_i)) + noise_i * I); host pointers.
  * While the n x n matrix fits one CU's LDS (n <= 160 for any nF <= 32, up to n = 176 for nF <= 16) ALL nodes are
  * scored by ONE kernel launch, one workgroup per node (Gram build, Cholesky, forward solve and reductions never
- * leave the CU); gpslc_gp_logpdf and gpslc_y_logpdf take the same path at those sizes.  Larger n: the general
- * tiled path, node by node.  Return value and gpslc_last_info (count entries) as for gpslc_gp_logpdf. */
+ * leave the CU); gpslc_gp_logpdf and gpslc_y_logpdf take the same path at those sizes.  Larger n: ONE batched pass of
+ * the general tiled path over all nodes (feature blocks zero-padded to the widest node with lengthscale-1 columns, which
+ * add +0.0 to every squared distance: scores bit-identical to node-by-node calls; 3 nodes cost 1.09 x one at n = 4096).
+ * Return value and gpslc_last_info (count entries) as for gpslc_gp_logpdf. */
 typedef struct gpslc_node {
     int32_t nF;            /* feature columns, 0..32 */
     int32_t reserved;
@@ -250,8 +252,8 @@ int gpslc_pack_load(const char* path, int64_t s0, int64_t s1, double* X, double*
 
 /* Accumulated HIP-event statistics since the last reset, recorded (on the launching stream) when the ctx was
  * created with GPSLC_FLAG_PROFILE: launches, total device milliseconds, total algorithmic work.  Kernel classes:
- *   0  tile_gemm_nt_kernel<1, 0, 0> in the factorisation of A (trailing updates: the dominant kernel)   work = flop
- *   1  tile_gemm_nt_kernel<1, 0, 1> in the factorisation of A (in-panel column update + panel solve)    work = flop
+ *   0  tile_gemm_nt_kernel<1, 0> in the factorisation of A (trailing updates: the dominant kernel)   work = flop
+ *   1  tile_fused_strip_kernel in the factorisation of A (in-panel column update + panel solve)        work = flop
  *   2  the predictive-draw kernels of a launch_draws call (normal generation + triangular product)      work = draws
  *   3  every f64-MFMA tile-update launch of the full-ITE-covariance path (W solve, SYRK, factor)        work = flop
  * gpslc_profile_get is class 0. */

@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of host CPU / tens of GB of host memory; opt in with GPSLC_RUN_SLOW=1")
 
 
 @pytest.fixture(scope="session")

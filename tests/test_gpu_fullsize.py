@@ -9,6 +9,8 @@ size-independent properties for all of them:
   * invariance of the SATE under a permutation of the instances;
   * independence of batch / stream / panel tuning.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -123,6 +125,26 @@ def test_unit_b_with_draws_n1024_default_jitter(gp):
             assert np.linalg.norm(out[:, col] - ref[:, col]) <= 1e-8 * lc_norm * np.linalg.norm(z[:, col])
 
 
+def test_unit_b_draw_n4096_default_jitter_against_the_literal_restatement(gp):
+    """Unit B at the size bench.py quotes it on (N = 4096, D 8, nU 2) with the reference's default 1e-10 jitter
+    (src/hyperparameters.jl:92): full ITE covariance + its factor + one draw with the caller's normals for one
+    (sample, level) pair, against the LITERAL restatement (src/estimation.jl:36-50, 82, 95-109: mean + chol(CovITE + jitter) z)
+    under the conditioning-aware bound of SURVEY §8d (tests/test_gpu_estimation.py uses the same rule); MeanITE too."""
+    n, D, K, S = 4096, 8, 2, 1
+    g, (X, T, Y, post) = _obj(gp, n, D, K, S)
+    doT = float(gp.synth.levels(T, 1)[0])
+    z = np.random.default_rng(2024).standard_normal((n, 1, S, 1))
+    _, _, mi, dr = gp.predict(g, [doT], want_mean_ite=True, spp=1, z=z, want_draws=True)
+    assert not g.ctx().last_info(S).any()
+    M, Cv = orc.ite_distributions([_sample(post, 0, D, K)], X, T, Y, doT)
+    ev = np.linalg.eigvalsh(Cv[0])
+    Lc = np.linalg.cholesky(Cv[0])
+    ref = M[0] + Lc @ z[:, 0, 0, 0]
+    bound = max(1e-8, 1e-15 * ev[-1] / ev[0]) * np.sqrt(ev[-1]) * np.linalg.norm(z) + 1e-9 * np.linalg.norm(ref)
+    assert np.linalg.norm(dr[0][:, 0] - ref) <= bound
+    assert np.max(np.abs(mi[:, 0, 0] - M[0])) <= 1e-6 * np.max(np.abs(M[0])) + 1e-12
+
+
 def test_unit_b_pairs_and_robust_factor_n2048(gp):
     """Full ITE covariance + its factor + draws across 16 x 16 tiles: 2 posterior samples x 2 levels in one sub-batch
     ((sample, level) pair batching), CovITE + 1e-6 I factorised by the substitution-based tiled Cholesky, draws with the
@@ -207,6 +229,60 @@ def test_config5_mixed_precision_n16384_against_the_fp64_oracle(gp):
     for l in range(2):
         assert abs(ms[1, l] - rm[l]) <= 1e-6 * abs(rm[l]) + 1e-12, (ms[1, l], rm[l])
         assert abs(vs[1, l] - rv[l]) <= 1e-6 * abs(rv[l]) + 1e-9 * p.yScale, (vs[1, l], rv[l])
+    # the MeanITE vector itself against the oracle (not only through its mean): fp64 structured restatement, doT = 1
+    m_ref = _structured_mean_ite(p, X, T, Y, 1.0)
+    assert np.max(np.abs(mi[:, 1, 1] - m_ref)) <= 1e-6 * np.max(np.abs(m_ref)) + 1e-12
+
+
+def _structured_mean_ite(p, X, T, Y, doT):
+    """MeanITE = D A^-1 Y of the structured restatement without forming CovITE (orc.structured_ite would: 2 GB and an
+    N^3 solve at N = 16384): same B, E, r, Cholesky and solves as oracle.structured_ite's mean."""
+    Bm, E = orc._base_and_e(p, X, T)
+    Tv = np.asarray(T, dtype=np.float64)
+    n = Tv.shape[0]
+    K = Bm * E
+    L = orc._chol_lower(K + p.yNoise * np.eye(n))
+    import scipy.linalg as sla
+    alpha = sla.solve_triangular(L, orc._tri_solve_lower(L, np.asarray(Y, dtype=np.float64)), lower=True, trans="T")
+    r = np.exp(-((Tv - doT) ** 2) / p.tyLS ** 2)
+    return (Bm * r[None, :] - K) @ alpha          # D_ij = B_ij (r_j - e_ij)
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("GPSLC_RUN_SLOW") != "1",
+                    reason="set GPSLC_RUN_SLOW=1: minutes of host CPU and ~60 GB of host memory (profiles/r03_config5_literal.md has the recorded run)")
+def test_config5_n16384_against_the_LITERAL_restatement_fp64_and_mixed(gp):
+    """BASELINE configs[4] shape, ONE unit, against the LITERAL restatement of the reference algorithm at full size
+    (5 kernel builds, 3 symmetric-indefinite solves, 4 GEMMs at N = 16384: src/likelihood.jl:8-52,
+    src/estimation.jl:46-47, 82, 116-121): MeanSATE, VarSATE and the whole MeanITE vector, in fp64 and in the
+    configuration's stated mixed mode (fp32 kernel build + fp64 Cholesky)."""
+    import time
+    try:
+        import psutil
+        if psutil.virtual_memory().available < 80e9:
+            pytest.skip("needs ~60 GB of host memory")
+    except ImportError:
+        pass
+    n, D, K, S = 16384, 16, 4, 1
+    X, T, Y, objid = gp.synth.make_dataset(n, D, binary_t=True)
+    post = gp.synth.make_posterior(n, D, K, S, objid)
+    p = _sample(post, 0, D, K)
+    t0 = time.time()
+    M, Cv = orc.ite_distributions([p], X, T, Y, 1.0)
+    rm, rv = orc.conditional_sate(M[0], Cv[0])
+    m_ref = np.array(M[0])
+    del M, Cv
+    print(f"\nliteral restatement at N={n}: {time.time() - t0:.0f} s; MeanSATE {rm!r} VarSATE {rv!r}")
+    for fp32 in (False, True):
+        g = gp.GPSLCObject(X, T, Y, post["U"], post["uyLS"], post["xyLS"], post["tyLS"], post["yNoise"], post["yScale"],
+                           fp32_kernel=fp32)
+        ms, vs, mi = gp.predict(g, [1.0], want_mean_ite=True)
+        em, ev = abs(ms[0, 0] - rm) / abs(rm), abs(vs[0, 0] - rv) / abs(rv)
+        ei = np.max(np.abs(mi[:, 0, 0] - m_ref)) / np.max(np.abs(m_ref))
+        print(f"{'fp32 kernel build + fp64 Cholesky' if fp32 else 'fp64'}: rel err MeanSATE {em:.3e} VarSATE {ev:.3e} MeanITE (max, rel. to max) {ei:.3e}")
+        assert abs(ms[0, 0] - rm) <= 1e-6 * abs(rm) + 1e-12
+        assert abs(vs[0, 0] - rv) <= 1e-6 * abs(rv) + 1e-9 * p.yScale
+        assert ei <= 1e-6
 
 
 def test_config4_shape_n4096_64_levels(gp):

@@ -10,6 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"          # file-name prefix under profiles/
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -20,20 +21,22 @@ def blob_sha(path):
 
 
 sha = blob_sha(os.path.join(ROOT, "causalgpslc.jl_amd", "csrc", "k_tilegemm.hip"))
-names = {"kernel_stats.md": "r02_bench_kernel_stats.md", "kernel_stats_unit_b.md": "r02_unit_b_kernel_stats.md",
-         "pmc_tile_gemm.md": "r02_pmc_tile_gemm.md", "pmc_fused.md": "r02_pmc_fused_in_panel.md",
-         "pmc_draws.md": "r02_pmc_draws.md"}
+names = {"kernel_stats.md": f"{rnd}_bench_kernel_stats.md", "kernel_stats_unit_b.md": f"{rnd}_unit_b_kernel_stats.md",
+         "pmc_tile_gemm.md": f"{rnd}_pmc_tile_gemm.md", "pmc_fused.md": f"{rnd}_pmc_fused_in_panel.md",
+         "pmc_draws.md": f"{rnd}_pmc_draws.md", "kernel_stats_c2.md": f"{rnd}_n1024_kernel_stats.md",
+         "pmc_gram.md": f"{rnd}_pmc_gram.md", "pmc_ite_mean.md": f"{rnd}_pmc_ite_mean.md"}
 for a, b in names.items():
-    shutil.copy(os.path.join(src, a), os.path.join(dst, b))
-for a, b in {"pmc_tile_gemm.json": "r02_pmc_tile_gemm.json", "pmc_fused.json": "r02_pmc_fused_in_panel.json",
-             "pmc_draws.json": "r02_pmc_draws.json"}.items():
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+for a, b in {"pmc_tile_gemm.json": f"{rnd}_pmc_tile_gemm.json", "pmc_fused.json": f"{rnd}_pmc_fused_in_panel.json",
+             "pmc_draws.json": f"{rnd}_pmc_draws.json"}.items():
     d = json.load(open(os.path.join(src, a)))
     d["kernel_src_sha"] = sha
     d["kernel_src"] = "causalgpslc.jl_amd/csrc/k_tilegemm.hip (git blob hash)"
-    d["note"] = ("FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate rocprofv3 --pmc passes, tools/profile_r02.sh; "
-                 "per-launch means")
+    d["note"] = ("FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate rocprofv3 --pmc passes, "
+                 f"tools/profile_{rnd}.sh; per-launch means")
     json.dump(d, open(os.path.join(dst, b), "w"), indent=1)
 for l in open(os.path.join(src, "trace.log")):
     if l.startswith('{"metric"'):
-        open(os.path.join(dst, "r02_bench_under_rocprof.json"), "w").write(l)
+        open(os.path.join(dst, f"{rnd}_bench_under_rocprof.json"), "w").write(l)
 print("profiles/ updated from", tag, "kernel sha", sha)
