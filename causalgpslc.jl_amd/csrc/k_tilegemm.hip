@@ -32,8 +32,6 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(1))) char* gchar_p;     // global address space kept through opaque (asm) copies
-typedef const __attribute__((address_space(1))) d2* gd2_p;
 
 // measurement-only paths (in-kernel stamps, timing-only variants) exist in the -DGPSLC_DIAG build only
 #ifdef GPSLC_DIAG
@@ -48,25 +46,7 @@ typedef const __attribute__((address_space(1))) d2* gd2_p;
 #define LROW 144                      // padded k-row (doubles)
 #define OPER_LDS (KS * LROW)          // doubles per operand per stage
 #define GEMM_LDS_BYTES (2 * 2 * OPER_LDS * 8)
-#ifndef SADDR_LOADS
-#define SADDR_LOADS 0
-#endif
-#ifndef STRIP_NT
-#define STRIP_NT 2       // A slabs and C tiles are streamed once per launch: non-temporal, so that they do not displace the shared
-                         // B(k, kk) slabs and inv(L_kk) in L2 (measured: fused kernel +1.8 %, profiles/r03_ab_experiments.md)
-#endif
-#ifndef STRIP_DIAG
-#define STRIP_DIAG 0
-#endif
-#ifndef STRIP_PIPE
-#define STRIP_PIPE 0
-#endif
-#ifndef STRIP_STAGGER
-#define STRIP_STAGGER 0
-#endif
-#ifndef FUSE_WD
 #define FUSE_WD 8                      // inv(L) fragments in flight ahead of their MFMAs (strip kernel)
-#endif
 
 __device__ __forceinline__ void tri_decode(int t, int& ii, int& jj) {
     // t = ii(ii+1)/2 + jj, 0 <= jj <= ii
@@ -198,27 +178,11 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                 // panel product of a short (augmented-row) tile: the chunks of A below its live rows are never
                 // used — point them at chunk 0 of their k-column's line instead of streaming zeros
                 const int ao = (!ACC && ((tid & 63) * 2) >= 16 * prow) ? (tid & ~63) * 2 : tid * 2;
-#if SADDR_LOADS
-                // the four 4 KiB quarters of a slab through four UNIFORM bases (scalar adds) + one 32-bit lane offset: the
-                // saddr form of global_load — no 64-bit VALU address arithmetic between the MFMAs (a VALU instruction
-                // there costs ~5.6 pipe clocks, profiles/r03_ab_experiments.md §5)
-                const unsigned va = (unsigned)ao * 8u, vb = (unsigned)tid * 16u;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    gchar_p qa = (gchar_p)(reinterpret_cast<const char*>(pa)) + 4096 * u;
-                    gchar_p qb = (gchar_p)(reinterpret_cast<const char*>(pb)) + 4096 * u;
-                    unsigned va_ = va, vb_ = vb;
-                    asm volatile("" : "+s"(qa), "+s"(qb), "+v"(va_), "+v"(vb_));
-                    xa[u] = *(gd2_p)(qa + va_);
-                    xb[u] = *(gd2_p)(qb + vb_);
-                }
-#else
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     xa[u] = *reinterpret_cast<const d2*>(pa + ao + 512 * u);
                     xb[u] = *reinterpret_cast<const d2*>(pb + (tid + 256 * u) * 2);
                 }
-#endif
             };
             auto lstore = [&](int buf, const d2 (&xa)[4], const d2 (&xb)[4]) {
 #pragma unroll
@@ -419,6 +383,9 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
 // 64 k clocks of second phase per item against 37 k of MFMA time, profiles/r02_fused_kernel_stamps.md.)
 // Summation order per output element: ascending k in the K loop, ascending column of X in the second phase — the
 // order of the quadrant kernel and of the separate panel product, so the factor is bit-identical.
+// The A(i, kk) slabs and the C tile are streamed exactly once per launch: they are loaded / stored NON-TEMPORAL so that
+// they do not displace the B(k, kk) panel (shared by the ~24 items of a matrix) and inv(L_kk) in L2 (+1.8 % on the
+// kernel, profiles/r03_ab_experiments.md §3).
 // ---------------------------------------------------------------------------------------
 template <int WD>
 __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
@@ -450,10 +417,6 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
 
     __shared__ int s_ticket;
     long long it = local;
-#if STRIP_STAGGER > 0
-    if ((int)blockIdx.x >= (G >> 1))
-        for (int i = 0; i < STRIP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     while (it < xc) {
         int ticket = 0;
         if (g.queue && tid == 0) ticket = atomicAdd(&g.queue[xcd], 1);
@@ -485,11 +448,7 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
                 for (int v = 0; v < 4; ++v)
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
-#if STRIP_NT >= 2
                         acc[m][n][v] = __builtin_nontemporal_load(Cl + (16 * n + 4 * v) * GP_TS + 16 * m);
-#else
-                        acc[m][n][v] = Cl[(16 * n + 4 * v) * GP_TS + 16 * m];
-#endif
         }
 
         if (nslab > 0 && !no_update) {
@@ -497,42 +456,13 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
             auto gload = [&](int s, d2 (&xa)[4], d2 (&xb)[4]) {
                 const int kk = g.k0 + (s >> 3);
                 const int so = (s & 7) * (KS * GP_TS);
-#if STRIP_DIAG == 2
-                const double* pa = tref_tile(g.A, b, ti, g.k0);
-#else
                 const double* pa = tref_tile(g.A, b, ti, kk) + so;
-#endif
-#if STRIP_DIAG == 1 || STRIP_DIAG == 2
-                const double* pb = tref_tile(g.B, b, tj, g.k0);
-#else
                 const double* pb = tref_tile(g.B, b, tj, kk) + so;
-#endif
-#if SADDR_LOADS
-                const unsigned vo = (unsigned)tid * 16u;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    gchar_p qa = (gchar_p)(reinterpret_cast<const char*>(pa)) + 4096 * u;
-                    gchar_p qb = (gchar_p)(reinterpret_cast<const char*>(pb)) + 4096 * u;
-                    unsigned vo_ = vo;
-                    asm volatile("" : "+s"(qa), "+s"(qb), "+v"(vo_));
-#if STRIP_NT >= 1
-                    xa[u] = __builtin_nontemporal_load((gd2_p)(qa + vo_));
-#else
-                    xa[u] = *(gd2_p)(qa + vo_);
-#endif
-                    xb[u] = *(gd2_p)(qb + vo_);
-                }
-#else
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-#if STRIP_NT >= 1
                     xa[u] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2));
-#else
-                    xa[u] = *reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2);
-#endif
                     xb[u] = *reinterpret_cast<const d2*>(pb + (tid + 256 * u) * 2);
                 }
-#endif
             };
             auto lstore = [&](int buf, const d2 (&xa)[4], const d2 (&xb)[4]) {
 #pragma unroll
@@ -545,7 +475,6 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
                 if (!live) return;
                 const double* pa = lA + buf * OPER_LDS + frow_a;
                 const double* pb = lB + buf * OPER_LDS + frow_b;
-#if STRIP_PIPE == 0
 #pragma unroll
                 for (int ks = 0; ks < KS / 4; ++ks) {
                     double af[2], bf[8];
@@ -558,36 +487,6 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
 #pragma unroll
                         for (int m = 0; m < 2; ++m) acc[m][n] = mfma_step<1>(bf[n], af[m], acc[m][n]);
                 }
-#else
-                // the first fragments of k-step ks + 1 (both row blocks, PN column blocks) are requested before the MFMAs of
-                // k-step ks are issued; the other column blocks arrive under the first 2 PN MFMAs of their k-step
-                constexpr int PN = STRIP_PIPE;
-                double afn[2], bfn[PN];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) afn[m] = pa[16 * m];
-#pragma unroll
-                for (int n = 0; n < PN; ++n) bfn[n] = pb[16 * n];
-#pragma unroll
-                for (int ks = 0; ks < KS / 4; ++ks) {
-                    double af[2], bf[8];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) af[m] = afn[m];
-#pragma unroll
-                    for (int n = 0; n < PN; ++n) bf[n] = bfn[n];
-#pragma unroll
-                    for (int n = PN; n < 8; ++n) bf[n] = pb[ks * 4 * LROW + 16 * n];
-                    if (ks + 1 < KS / 4) {
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) afn[m] = pa[(ks + 1) * 4 * LROW + 16 * m];
-#pragma unroll
-                        for (int n = 0; n < PN; ++n) bfn[n] = pb[(ks + 1) * 4 * LROW + 16 * n];
-                    }
-#pragma unroll
-                    for (int n = 0; n < 8; ++n)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) acc[m][n] = mfma_step<1>(bf[n], af[m], acc[m][n]);
-                }
-#endif
             };
             gload(0, ra, rb);
             lstore(0, ra, rb);
@@ -636,23 +535,14 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
                                 if (++pv == 4) { pv = 0; if (++pn > pc) { pn = 0; ++pc; } }
                             }
                             ++q;
-#if STRIP_DIAG == 3
-                            st[0][v] += w * acc[0][n][v]; st[1][v] += w * acc[1][n][v];   // timing only: no second-phase MFMAs
-#else
                             st[0] = mfma_step<0>(w, acc[0][n][v], st[0]);
                             st[1] = mfma_step<0>(w, acc[1][n][v], st[1]);
-#endif
                         }
                     }
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-#if STRIP_NT >= 2
                     __builtin_nontemporal_store(st[0][v], Co + (16 * nc + 4 * v) * GP_TS);
                     __builtin_nontemporal_store(st[1][v], Co + (16 * nc + 4 * v) * GP_TS + 16);
-#else
-                    Co[(16 * nc + 4 * v) * GP_TS] = st[0][v];
-                    Co[(16 * nc + 4 * v) * GP_TS + 16] = st[1][v];
-#endif
                 }
             }
         }
