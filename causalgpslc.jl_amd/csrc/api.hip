@@ -640,6 +640,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
             IteMeanArgs ia{};
             ia.X = io.X; ia.T = c->dT; ia.p = io.p; ia.s0 = s0; ia.S = io.S;
             ia.n = n; ia.nX = io.nX; ia.nU = io.nU; ia.nt = nt; ia.L = L; ia.doT = io.doT; ia.alpha = alpha;
+            ia.Y = io.Y; ia.y_sstride = io.y_sstride; ia.yNoise = io.p.yNoise;
             ia.f32 = (c->flags & GPSLC_FLAG_FP32_KERNEL) ? 1 : 0;
             ia.binary_t = c->binary_t ? 1 : 0;
             if (meanITE) {

@@ -167,6 +167,9 @@ struct IteMeanArgs {
     const double* X; const double* T; SampleParams p; long long s0; long long S;
     int n, nX, nU, nt, L; const double* doT;
     const double* alpha;   // [b][Np]
+    const double* Y;       // right-hand side alpha solves for: A alpha = Y (sample s at Y + s*y_sstride)
+    long long y_sstride;
+    const double* yNoise;  // S (= p.yNoise; kept separate so that the generic node paths can pass their own)
     double* meanITE;       // element (i, s, l) at i*si + s*ss + l*sl
     long long si, ss, sl;
     int f32;

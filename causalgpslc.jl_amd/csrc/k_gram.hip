@@ -160,12 +160,14 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
                 const RT Bq = (RT)ys * RbfMath<RT>::exp_neg_t(-lux[p], etab);
                 const RT Eq = BIN ? (dt == (RT)0 ? (RT)1 : ew) : RbfMath<RT>::exp_neg_t(-((dt * dt) * wt), etab);
                 double Bv, Kv, Av;
+                // K = B .* E with the product taken in fp64 (exact for two fp32 factors): every consumer of K agrees on it to
+                // the last bit whichever precision evaluated the kernel
                 if (FAST) {
-                    Bv = (double)Bq; Kv = (double)(Bq * Eq); Av = Kv;
+                    Bv = (double)Bq; Kv = (double)Bq * (double)Eq; Av = Kv;
                 } else {
                     const bool inside = (gi < n) && (gj < n);
                     Bv = inside ? (double)Bq : 0.0;
-                    Kv = inside ? (double)(Bq * Eq) : 0.0;
+                    Kv = inside ? (double)Bq * (double)Eq : 0.0;
                     // diagonal: + yNoise inside, identity on the padding
                     Av = (gi == gj) ? (inside ? Kv + yn : 1.0) : Kv;
                 }

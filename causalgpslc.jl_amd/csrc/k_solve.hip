@@ -83,22 +83,24 @@ void launch_backsolve(const BackArgs& a, int nbatch, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------
-// MeanITE_i(l) = sum_j B_ij (r_j(l) - e_ij) alpha_j   (src/estimation.jl:46 with
-// D = Ks' - K formed element-wise so that doT == T gives exact zeros, test/estimation.jl:6-66).
-// One workgroup per (row block, sample); levels are processed LC at a time.
+// MeanITE (src/estimation.jl:46):  MeanITE = (Ks' - K) alpha,  alpha = A^-1 Y,  Ks'_ij = B_ij r_j(l),  K = B .* E.
+// Round 3: K alpha needs no second pass over the pairs — A alpha = Y, so  K alpha = Y - yNoise alpha  comes from the solve
+// itself, and
+//     MeanITE_i(l) = sum_j B_ij (r_j(l) alpha_j)  -  (Y_i - yNoise alpha_i)
+// costs ONE exp per pair (B_ij) instead of two (the e_ij of round 1/2: 56 -> 36 fp64-rate instructions per pair).
+// Row i of D = Ks' - K is identically zero in the reference's own arithmetic whenever T_i == doT ((T_j - doT)^2 and
+// (T_i - T_j)^2 are then the same square, so Ks'_ij == K_ij bit for bit): the reference returns an exact 0.0 for such an
+// instance (test/estimation.jl:6-66 is the n = 1 case) and so does this kernel.
+// One workgroup per (row block, sample); levels are processed LCT at a time.
 // ---------------------------------------------------------------------------------------
-template <int FREG, int LCT, typename RT, int RB, int BIN>
+template <int FREG, int LCT, typename RT, int RB>
 __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
-    // RB row blocks per workgroup: every broadcast LDS read of a column's features / r / alpha serves RB
-    // rows of the same thread (the LDS pipe, not the fp64 VALU, bounded the RB = 1 form)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = a.nU + a.nX;
     double* etab = sm;                     // [32] 2^(j/32): table-driven exp (gp_math.h)
-    double* al = etab + GP_EXP_TAB_DOUBLES;   // [128]
-    double* rl = al + GP_TS;               // [LCT][128]
+    double* rl = etab + GP_EXP_TAB_DOUBLES;   // [LCT][128]  r_j(l) * alpha_j of the staged column block
     double* red = rl + LCT * GP_TS;        // [RB][128][LCT]
     RT* fc = reinterpret_cast<RT*>(red + RB * GP_TS * LCT);   // [FREG][128] column features / LS (zero rows beyond F)
-    RT* tcs = fc + FREG * GP_TS;           // [128]
     const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;
     const int ib = blockIdx.x;
     const long long b = blockIdx.y, s = a.s0 + b;
@@ -112,21 +114,17 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
     };
     int gi[RB];
     RT af[RB][FREG];   // this thread's rows' features / LS
-    RT tri[RB];
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
         gi[q] = (ib * RB + q) * GP_TS + r;
 #pragma unroll
         for (int f = 0; f < FREG; ++f) af[q][f] = (RT)((f < F && gi[q] < n) ? feat_src(f)[gi[q]] * feat_il(f) : 0.0);
-        tri[q] = (RT)((gi[q] < n) ? a.T[gi[q]] : 0.0);
     }
     const double ys = a.p.yScale[s];
     const double tl = a.p.tyLS[s];
     const double wt = 1.0 / (tl * tl);
     const RT wtq = (RT)wt;
     gp_exp_tab_stage(etab, tid);
-    __syncthreads();
-    const RT ewq = RbfMath<RT>::exp_neg_t(-wtq, etab);
     const double* alpha = a.alpha + b * Np;
 
     for (int l0 = 0; l0 < a.L; l0 += LCT) {
@@ -143,18 +141,13 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
                 const int g = jt * GP_TS + cc;
                 fc[idx] = (RT)((f < F && g < n) ? feat_src(f)[g] * feat_il(f) : 0.0);
             }
-            if (tid < GP_TS) {
-                const int g = jt * GP_TS + tid;
-                tcs[tid] = (RT)((g < n) ? a.T[g] : 0.0);
-                al[tid] = (g < n) ? alpha[g] : 0.0;
-            }
             for (int idx = tid; idx < LCT * GP_TS; idx += 256) {
                 const int ll = idx >> 7, cc = idx & 127;
                 const int g = jt * GP_TS + cc;
                 double v = 0.0;
                 if (ll < nl && g < n) {
                     const RT dt = (RT)a.T[g] - (RT)a.doT[l0 + ll];
-                    v = (double)RbfMath<RT>::exp_neg_t(-((dt * dt) * wtq), etab);
+                    v = (double)RbfMath<RT>::exp_neg_t(-((dt * dt) * wtq), etab) * alpha[g];
                 }
                 rl[idx] = v;
             }
@@ -165,8 +158,6 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
                 RT cf[FREG];
 #pragma unroll
                 for (int f = 0; f < FREG; ++f) cf[f] = fc[f * GP_TS + c];
-                const RT tc = tcs[c];
-                const double alc = al[c];
                 double rlc[LCT];
 #pragma unroll
                 for (int ll = 0; ll < LCT; ++ll) rlc[ll] = rl[ll * GP_TS + c];
@@ -178,12 +169,9 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
                         const RT d = af[q][f] - cf[f];
                         lux = fma(d, d, lux);
                     }
-                    const RT dt = tri[q] - tc;
                     const double Bv = (double)((RT)ys * RbfMath<RT>::exp_neg_t(-lux, etab));
-                    const double Ev = (double)(BIN ? (dt == (RT)0 ? (RT)1 : ewq) : RbfMath<RT>::exp_neg_t(-((dt * dt) * wtq), etab));
-                    const double ba = Bv * alc;
 #pragma unroll
-                    for (int ll = 0; ll < LCT; ++ll) acc[q][ll] = fma(ba, rlc[ll] - Ev, acc[q][ll]);
+                    for (int ll = 0; ll < LCT; ++ll) acc[q][ll] = fma(Bv, rlc[ll], acc[q][ll]);
                 }
             }
         }
@@ -197,28 +185,33 @@ __global__ __launch_bounds__(256) void ite_mean_kernel(IteMeanArgs a) {
         __syncthreads();
         if (h == 0) {
 #pragma unroll
-            for (int q = 0; q < RB; ++q)
+            for (int q = 0; q < RB; ++q) {
+                if (gi[q] >= n) continue;
+                // (K alpha)_i = Y_i - yNoise alpha_i: alpha solves (K + yNoise I) alpha = Y
+                const double ka = a.Y[s * a.y_sstride + gi[q]] - a.yNoise[s] * alpha[gi[q]];
+                const double ti = a.T[gi[q]];
 #pragma unroll
                 for (int ll = 0; ll < LCT; ++ll)
-                    if (ll < nl && gi[q] < n)
+                    if (ll < nl) {
+                        const double v = (acc[q][ll] + red[(q * GP_TS + r) * LCT + ll]) - ka;
                         a.meanITE[(long long)gi[q] * a.si + s * a.ss + (long long)(l0 + ll) * a.sl] =
-                            acc[q][ll] + red[(q * GP_TS + r) * LCT + ll];
+                            (ti == a.doT[l0 + ll]) ? 0.0 : v;
+                    }
+            }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // MeanITE for many intervention levels on the MFMA (L > 4, fp64):
-//   MeanITE[i, l] = sum_j B_ij (r_j(l) alpha_j)  -  sum_j (B_ij e_ij) alpha_j
-// = (B R)[i, l] - (K alpha)[i],  R[j, l] = r_j(l) alpha_j  — a (128 x N)(N x 64) product per row block.
-// No operand tile goes through LDS: the f64 16x16x4 MFMA wants one element per lane, and each lane
-// computes exactly its own B_rc (row = 16m + lane&15, column = 4kk + lane>>4) and K_rc = B_rc e_rc from
-// the staged features; R is staged per 64-column chunk.  The K alpha term runs as a second MFMA product
-// with the same k order: when doT == T for every instance r == e == 1, B and K, R[:, l] and alpha are
-// bit-identical, so both MFMA chains produce identical sums and the difference is exactly 0.0
-// (test/estimation.jl:6-66).
+//   MeanITE[i, l] = sum_j B_ij (r_j(l) alpha_j)  -  (Y_i - yNoise alpha_i)
+// = (B R)[i, l] - (K alpha)[i],  R[j, l] = r_j(l) alpha_j  — a (128 x N)(N x 64) product per row block; K alpha from
+// the solve itself (A alpha = Y; see ite_mean_kernel), so the pair loop evaluates one exp (B_ij) and no e_ij.
+// No operand tile goes through LDS: the f64 16x16x4 MFMA wants one element per lane, and each lane computes exactly its
+// own B_rc (row = 16m + lane&15, column = 4kk + lane>>4) from the staged features; R is staged per 64-column chunk.
+// Instances with T_i == doT_l get the reference's exact 0.0 (row i of Ks' - K is identically zero there).
 // One workgroup = 128 rows x up to 64 levels; wave w owns rows 32w..32w+31 (2 row sub-tiles x 4 level
-// sub-tiles = 8 accumulators + 2 for K alpha).
+// sub-tiles = 8 accumulators).
 // ---------------------------------------------------------------------------------------
 typedef double d4s __attribute__((ext_vector_type(4)));
 typedef double d2s __attribute__((ext_vector_type(2)));
@@ -226,7 +219,7 @@ typedef double d2s __attribute__((ext_vector_type(2)));
 #define IM_RLD 80         // padded row of the R chunk (doubles): conflict-free ds_read_b64 across k rows
 #define IM_NL 64          // levels per pass
 
-template <int FREG, int BIN>   // FREG > 0: this lane's two rows' features live in registers (F <= FREG); 0: read from LDS
+template <int FREG>   // FREG > 0: this lane's two rows' features live in registers (F <= FREG); 0: read from LDS
 __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int F = a.nU + a.nX;
@@ -234,10 +227,7 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
     double* fr = etab + GP_EXP_TAB_DOUBLES;  // [F][128] row features / LS
     const int FSL = FREG > F ? FREG : F;
     double* fc = fr + F * GP_TS;             // [max(F, FREG)][IM_CC] column features / LS
-    double* trs = fc + FSL * IM_CC;          // [128]
-    double* tcs = trs + GP_TS;               // [IM_CC]
-    double* al = tcs + IM_CC;                // [IM_CC]
-    double* R = al + IM_CC;                  // [IM_CC][IM_RLD]  r_j(l) * alpha_j
+    double* R = fc + FSL * IM_CC;            // [IM_CC][IM_RLD]  r_j(l) * alpha_j
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int ib = blockIdx.x;
@@ -255,10 +245,6 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
         const int g = ib * GP_TS + rr;
         fr[idx] = (g < n) ? feat_src(f)[g] * feat_il(f) : 0.0;
     }
-    if (tid < GP_TS) {
-        const int g = ib * GP_TS + tid;
-        trs[tid] = (g < n) ? a.T[g] : 0.0;
-    }
     const double ys = a.p.yScale[s];
     const double tl = a.p.tyLS[s];
     const double wt = 1.0 / (tl * tl);
@@ -266,7 +252,6 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
     gp_exp_tab_stage(etab, tid);
     const int r0 = 32 * wave + li;           // this lane's rows: r0 and r0 + 16
     __syncthreads();
-    const double ew = gp_exp_neg_tab(-wt, etab);
     double af0[FREG > 0 ? FREG : 1], af1[FREG > 0 ? FREG : 1];
     if (FREG > 0) {
 #pragma unroll
@@ -279,13 +264,11 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
     for (int l0 = 0; l0 < a.L; l0 += IM_NL) {
         const int nl = min(IM_NL, a.L - l0);
         const int nq = (nl + 15) >> 4;          // live 16-level sub-tiles of this pass (wave-uniform)
-        d4s acc[2][4], acck[2];
+        d4s acc[2][4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            acck[m] = (d4s){0.0, 0.0, 0.0, 0.0};
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[m][q] = (d4s){0.0, 0.0, 0.0, 0.0};
-        }
         for (int c0 = 0; c0 < Np; c0 += IM_CC) {
             __syncthreads();
             const int FS = FREG > F ? FREG : F;      // staged feature rows (zero beyond F)
@@ -293,11 +276,6 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
                 const int f = idx / IM_CC, cc = idx - f * IM_CC;
                 const int g = c0 + cc;
                 fc[idx] = (f < F && g < n) ? feat_src(f)[g] * feat_il(f) : 0.0;
-            }
-            if (tid < IM_CC) {
-                const int g = c0 + tid;
-                tcs[tid] = (g < n) ? a.T[g] : 0.0;
-                al[tid] = (g < n) ? alpha[g] : 0.0;
             }
             for (int idx = tid; idx < IM_CC * IM_NL; idx += 256) {
                 const int cc = idx >> 6, ll = idx & 63;      // consecutive threads -> consecutive levels
@@ -310,7 +288,6 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
                 R[cc * IM_RLD + ll] = v;
             }
             __syncthreads();
-            const double t0 = trs[r0], t1 = trs[r0 + 16];
 #pragma unroll 2
             for (int kk = 0; kk < IM_CC / 4; ++kk) {
                 const int cc = 4 * kk + lq;            // this lane's column inside the chunk
@@ -332,13 +309,7 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
                         lux1 = fma(d1, d1, lux1);
                     }
                 }
-                const double tc = tcs[cc];
-                const double dt0 = t0 - tc, dt1 = t1 - tc;
                 const double B0 = ys * gp_exp_neg_tab(-lux0, etab), B1 = ys * gp_exp_neg_tab(-lux1, etab);
-                const double E0 = BIN ? (dt0 == 0.0 ? 1.0 : ew) : gp_exp_neg_tab(-((dt0 * dt0) * wt), etab);
-                const double E1 = BIN ? (dt1 == 0.0 ? 1.0 : ew) : gp_exp_neg_tab(-((dt1 * dt1) * wt), etab);
-                const double K0 = B0 * E0, K1 = B1 * E1;
-                const double av = (li == 0) ? al[cc] : 0.0;       // alpha as a one-column right operand
                 const double* Rrow = R + cc * IM_RLD + li;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -348,42 +319,37 @@ __global__ __launch_bounds__(256, 2) void ite_mean_mfma_kernel(IteMeanArgs a) {
                         acc[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(rf, B1, acc[1][q], 0, 0, 0);
                     }
                 }
-                acck[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, K0, acck[0], 0, 0, 0);
-                acck[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, K1, acck[1], 0, 0, 0);
             }
         }
-        // acc[m][q][v] = (B R)[row 32w + 16m + li][level 16q + lq + 4v]; (K alpha)[row] sits in lane li, v = 0
+        // acc[m][q][v] = (B R)[row 32w + 16m + li][level 16q + lq + 4v]
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const double ka = __shfl(acck[m][0], li, 64);
             const int gi = ib * GP_TS + 32 * wave + 16 * m + li;
             if (gi < n) {
+                const double ka = a.Y[s * a.y_sstride + gi] - a.yNoise[s] * alpha[gi];     // (K alpha)_i from A alpha = Y
+                const double ti = a.T[gi];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int ll = 16 * q + lq + 4 * v;
                         if (ll < nl)
-                            a.meanITE[(long long)gi * a.si + s * a.ss + (long long)(l0 + ll) * a.sl] = acc[m][q][v] - ka;
+                            a.meanITE[(long long)gi * a.si + s * a.ss + (long long)(l0 + ll) * a.sl] =
+                                (ti == a.doT[l0 + ll]) ? 0.0 : acc[m][q][v] - ka;
                     }
             }
         }
     }
 }
 
-template <int FREG, int BIN>
-static void launch_ite_mean_mfma_tb(const IteMeanArgs& a, int nbatch, hipStream_t st) {
-    const int F = a.nU + a.nX;
-    const int FS = FREG > F ? FREG : F;
-    const int bytes = (GP_EXP_TAB_DOUBLES + F * GP_TS + FS * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8;
-    static DeviceOnce attr_set;
-    lds_opt_in(attr_set, (const void*)ite_mean_mfma_kernel<FREG, BIN>, (GP_EXP_TAB_DOUBLES + MAXF * GP_TS + MAXF * IM_CC + GP_TS + 2 * IM_CC + IM_CC * IM_RLD) * 8);
-    hipLaunchKernelGGL((ite_mean_mfma_kernel<FREG, BIN>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
-}
 template <int FREG>
 static void launch_ite_mean_mfma_t(const IteMeanArgs& a, int nbatch, hipStream_t st) {
-    if (a.binary_t) launch_ite_mean_mfma_tb<FREG, 1>(a, nbatch, st);
-    else launch_ite_mean_mfma_tb<FREG, 0>(a, nbatch, st);
+    const int F = a.nU + a.nX;
+    const int FS = FREG > F ? FREG : F;
+    const int bytes = (GP_EXP_TAB_DOUBLES + F * GP_TS + FS * IM_CC + IM_CC * IM_RLD) * 8;
+    static DeviceOnce attr_set;
+    lds_opt_in(attr_set, (const void*)ite_mean_mfma_kernel<FREG>, (GP_EXP_TAB_DOUBLES + MAXF * GP_TS + MAXF * IM_CC + IM_CC * IM_RLD) * 8);
+    hipLaunchKernelGGL((ite_mean_mfma_kernel<FREG>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
 }
 static void launch_ite_mean_mfma(const IteMeanArgs& a, int nbatch, hipStream_t st) {
     const int F = a.nU + a.nX;
@@ -395,19 +361,13 @@ static void launch_ite_mean_mfma(const IteMeanArgs& a, int nbatch, hipStream_t s
     else launch_ite_mean_mfma_t<0>(a, nbatch, st);
 }
 
-template <int FREG, int LCT, typename RT, int BIN>
-static void launch_ite_mean_tb(const IteMeanArgs& a, int nbatch, hipStream_t st) {
-    constexpr int RB = 1;     // row blocks per workgroup (2 measured slower: occupancy)
-    const int bytes = (GP_EXP_TAB_DOUBLES + GP_TS + (1 + RB) * LCT * GP_TS) * 8 + (FREG * GP_TS + GP_TS) * (int)sizeof(RT);
-    static DeviceOnce attr_set;
-    lds_opt_in(attr_set, (const void*)ite_mean_kernel<FREG, LCT, RT, RB, BIN>, bytes);
-    hipLaunchKernelGGL((ite_mean_kernel<FREG, LCT, RT, RB, BIN>), dim3((a.nt + RB - 1) / RB, nbatch), dim3(256), bytes, st, a);
-}
 template <int FREG, int LCT, typename RT>
 static void launch_ite_mean_t(const IteMeanArgs& a, int nbatch, hipStream_t st) {
-    // binary treatments as a template parameter: a runtime flag puts the exp behind a branch in the hot loop
-    if (a.binary_t) launch_ite_mean_tb<FREG, LCT, RT, 1>(a, nbatch, st);
-    else launch_ite_mean_tb<FREG, LCT, RT, 0>(a, nbatch, st);
+    constexpr int RB = 1;     // row blocks per workgroup (2 measured slower: occupancy)
+    const int bytes = (GP_EXP_TAB_DOUBLES + (1 + RB) * LCT * GP_TS) * 8 + (FREG * GP_TS) * (int)sizeof(RT);
+    static DeviceOnce attr_set;
+    lds_opt_in(attr_set, (const void*)ite_mean_kernel<FREG, LCT, RT, RB>, bytes);
+    hipLaunchKernelGGL((ite_mean_kernel<FREG, LCT, RT, RB>), dim3((a.nt + RB - 1) / RB, nbatch), dim3(256), bytes, st, a);
 }
 template <int FREG, typename RT>
 static void launch_ite_mean_f(const IteMeanArgs& a, int nbatch, hipStream_t st) {
