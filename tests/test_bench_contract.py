@@ -54,7 +54,7 @@ def test_launcher_counts_gpus_without_touching_them():
 
 
 def test_committed_bench_line_carries_the_contract_keys():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "sate_rel_err", "units"):
         assert k in d, k
@@ -63,3 +63,9 @@ def test_committed_bench_line_carries_the_contract_keys():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
     assert d["sate_rel_err"]["ok"] and d["sate_rel_err"]["mean"] < 1e-6 and d["sate_rel_err"]["var"] < 1e-6
     assert {"A", "B", "C"} <= set(d["units"])
+    # round 3: every number of the line is oracle-backed and no roofline fraction exceeds 1
+    assert d["units"]["B"]["parity"]["ok"] and d["units"]["B"]["parity"]["draw_err"] <= d["units"]["B"]["parity"]["draw_bound"]
+    assert 0 < d["units"]["C"]["frac"] <= 1 and 0 < d["units"]["B"]["frac"] <= 1 and 0 < d["roofline"]["frac"] <= 1
+    assert d["config4"]["levels"] == 64 and d["config4"]["parity"]["ok"]
+    assert {"c2", "c5"} <= set(d["configs"]) and all(c["parity"]["ok"] for c in d["configs"].values())
+    assert d["units"]["A"]["ceiling_shared_datapath_units_per_s"] < d["units"]["A"]["ceiling_units_per_s"]
