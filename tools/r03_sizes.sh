@@ -1,7 +1,7 @@
 #!/bin/bash
-# unit A across problem sizes, production library
+# unit A across problem sizes, production library — round 3
 cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-units"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-units --no-config4 --no-configs"
 run() { tag=$1; shift; timeout -k 10 300 $B "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d.get('roofline',{}); s=r.get('second_kernel',{})
