@@ -56,12 +56,14 @@ mutable struct Ctx
     nX::Int
     nU::Int
     data::Any                      # (X, T, Y) as handed to set_data! (Float64 host copies), or nothing
+    cov::Any                       # the dense covariance handed to gpslc_mvn_logpdf last (identity-compared), or nothing
+    cov_chol::Any                  # its host factor, for prior draws (HipMvNormal's `random`), or nothing
     function Ctx(n::Integer, nX::Integer, nU::Integer; device::Integer=0, flags::Integer=FLAG_DEFAULT)
         r = Ref{Ptr{Cvoid}}(C_NULL)
         st = ccall((:gpslc_create, lib), Cint, (Ref{Ptr{Cvoid}}, Cint, Int64, Int32, Int32, UInt32),
                    r, device, n, nX, nU, flags)
         st == 0 || error("gpslc_create: status $st")
-        c = new(r[], n, nX, nU, nothing)
+        c = new(r[], n, nX, nU, nothing, nothing, nothing)
         finalizer(destroy!, c)
         c
     end
@@ -89,7 +91,9 @@ end
 # marshalling: Float64 column-major arrays; Bool / Int inputs promote as they do on subtraction (src/kernel.jl:17)
 f64(x::Nothing) = nothing
 f64(x::Array{Float64}) = x
-f64(x::AbstractArray) = convert(Array{Float64}, collect(x))
+f64(x::AbstractArray{<:Real}) = convert(Array{Float64}, collect(x))
+f64(x::AbstractArray) = throw(ArgumentError("GPSLCHip.f64: an array of $(eltype(x)) is not a numeric block — nested " *
+    "vectors (a `Confounders` value such as [[1.0]]) go through `_umat` first"))
 f64(x::Number) = Float64[x]
 ptr(::Nothing) = Ptr{Float64}(C_NULL)
 ptr(x::Array{Float64}) = pointer(x)
@@ -364,6 +368,54 @@ function kctx()
     KCTX[]::Ctx
 end
 
+"""dctx(n, nX, nU): a context of that shape, re-used across calls (the data set is handed over again by the caller with
+`set_data!`: n (nX + 2) doubles).  The reference's parameter-level functions — conditionalITE(uyLS, …, U, X, T, Y, doT),
+likelihoodDistribution — carry their data in the arguments and are called in loops (src/estimation.jl:78-84): a context
+per call would put hipMalloc + stream creation inside that loop.  At most 8 shapes are kept."""
+const DCTX = Dict{NTuple{3,Int},Ctx}()
+function dctx(n::Integer, nX::Integer, nU::Integer)
+    key = (Int(n), Int(nX), Int(nU))
+    c = get(DCTX, key, nothing)
+    if c === nothing || c.h == C_NULL
+        if length(DCTX) >= 8
+            foreach(destroy!, values(DCTX))
+            empty!(DCTX)
+        end
+        c = Ctx(n, nX, nU)
+        DCTX[key] = c
+    end
+    c
+end
+
+"""nctx(n): the context of the Gen-node calls, which carry their feature block and target in the arguments."""
+nctx(n::Integer) = dctx(n, 0, 0)
+
+"""One node score: log N(target; 0, scale exp.(rbfKernelLog(F, F, ls)) + noise I), F n x nF, ls nF."""
+function gp_score(c::Ctx, F::Matrix{Float64}, ls::Vector{Float64}, scale::Float64, noise::Float64, target::Vector{Float64})
+    size(F, 2) == length(ls) || throw(DimensionMismatch("gp_score: $(size(F, 2)) feature columns, $(length(ls)) lengthscales"))
+    GC.@preserve F ls target begin
+        nodes_logpdf(c, [GPSLCNode(size(F, 2), 0, pointer(F), pointer(ls), scale, noise, pointer(target))])[1]
+    end
+end
+
+"""chol(scale exp.(rbfKernelLog(F, F, ls)) + noise I) * z for the caller's standard normals z (n <= 640)."""
+function draw(c::Ctx, F::Matrix{Float64}, ls::Vector{Float64}, scale::Float64, noise::Float64, z::Vector{Float64})
+    size(F, 2) == length(ls) || throw(DimensionMismatch("draw: $(size(F, 2)) feature columns, $(length(ls)) lengthscales"))
+    GC.@preserve F ls z begin
+        nodes_draw(c, [GPSLCNode(size(F, 2), 0, pointer(F), pointer(ls), scale, noise, pointer(z))])[:, 1]
+    end
+end
+
+"""log N(x; 0, covscale * cov): `cov` is handed to the library when it is not (by identity) the matrix the context
+already holds — SigmaU is one constant matrix per data set (src/utils.jl:17-33) — and re-used otherwise."""
+function mvn_score(c::Ctx, cov::Matrix{Float64}, covscale::Float64, x::Vector{Float64})
+    if c.cov !== cov
+        mvn_logpdf(c, cov, nothing, nothing)          # S = 0: hand over + validate (PosDefException if not PD)
+        c.cov, c.cov_chol = cov, nothing
+    end
+    mvn_logpdf(c, nothing, covscale, reshape(x, :, 1))[1]
+end
+
 end # module GPSLCHip
 
 
@@ -373,40 +425,107 @@ end # module GPSLCHip
 # =====================================================================================================================
 
 import LinearAlgebra
+import Random
 
-# ---- one Ctx + one posterior pack per GPSLCObject (the object is immutable: cache by identity) -------------------
-const _GPSLC_CTX = IdDict{Any,GPSLCHip.Ctx}()
-const _GPSLC_PACK = IdDict{Any,GPSLCHip.Pack}()
+# ---- argument forms -----------------------------------------------------------------------------------------------
+# `Confounders` (src/types.jl:85-94) is a union of an n x nU matrix, a length-n vector (nU = 1) and NESTED vectors —
+# individual i is U[i], as the Vector{Vector} method of rbfKernelLog reads it (src/kernel.jl:34-42); the reference's own
+# estimation tests pass U = [[1.0]] (test/test_data.jl:42).  Every place where a U enters the shim goes through _umat,
+# and nU is the column count of ITS result — never size(U, 2), which is 1 for every vector form.
+_umat(::Nothing) = nothing
+_umat(U::AbstractMatrix{<:Real}) = GPSLCHip.f64(U)                                      # n x nU
+_umat(U::AbstractVector{<:Real}) = reshape(GPSLCHip.f64(U), :, 1)                       # n x 1
+_umat(U::AbstractVector{<:AbstractVector}) =                                            # n vectors of length nU -> n x nU
+    Matrix{Float64}(permutedims(reduce(hcat, [GPSLCHip.f64(collect(u)) for u in U])))
+function _umat(U)                                                                       # PersistentVector and friends
+    V = [u for u in U]                                # a comprehension narrows the element type (collect keeps Any)
+    V isa Union{AbstractVector{<:Real},AbstractVector{<:AbstractVector}} ||
+        throw(ArgumentError("_umat: cannot read a $(typeof(U)) as confounders (n x nU matrix, length-n vector or n vectors of length nU)"))
+    _umat(V)
+end
+_ncols(::Nothing) = 0
+_ncols(M::AbstractMatrix) = size(M, 2)
 
-"""ctx(g): the device context holding g.X, g.T, g.Y (src/types.jl:249-258), created on first use."""
-function ctx(g::GPSLCObject)
-    get!(_GPSLC_CTX, g) do
+_ls(LS::Number) = Float64[LS]
+_ls(LS) = GPSLCHip.f64(vec(collect(LS)))
+"""A lengthscale argument for a d-column feature block: a scalar applies to every column (src/kernel.jl:17 broadcasts)."""
+_lsfor(::Nothing, d::Integer) = Float64[]
+_lsfor(LS::Number, d::Integer) = fill(Float64(LS), d)
+_lsfor(LS, d::Integer) = (v = _ls(LS); @assert(length(v) == d, "vector lengthscale doesn't match individual"); v)
+_mat(X::AbstractMatrix) = GPSLCHip.f64(X)
+_mat(X::AbstractVector) = reshape(GPSLCHip.f64(X), :, 1)
+"""[U | X | T ...] as one n x nF Float64 block (parts that are `nothing` are skipped; Bool treatments become 0.0 / 1.0)
+and the matching lengthscale vector."""
+function _features(parts_and_ls::Pair...)
+    blocks = Matrix{Float64}[]
+    ls = Float64[]
+    for (part, LS) in parts_and_ls
+        part === nothing && continue
+        M = _umat(part)
+        push!(blocks, M)
+        append!(ls, _lsfor(LS, size(M, 2)))
+    end
+    Matrix{Float64}(reduce(hcat, blocks)), ls
+end
+_dot(doT::Union{Bool,Float64}) = Float64(doT)
+_dot(doT) = throw(ArgumentError("vector interventions: fill(doT, n) of a vector has no rbfKernelLog method in the " *
+                                "reference either (src/likelihood.jl:27-28)"))
+
+# ---- the device side of a GPSLCObject: one Ctx + one posterior pack, for as long as the object lives ----------------
+# GPSLCObject is an immutable struct (src/types.jl:249-258): it can carry neither a finalizer nor be a WeakKeyDict key.
+# Its `posteriorSamples::Vector{Any}` is the one field with an identity and a lifetime of its own, so the entry is keyed by
+# objectid(g.posteriorSamples), holds only a WeakRef to that vector (checked on every lookup: ids can be re-used), and a
+# finalizer on the vector frees the device context — hundreds of MB of HBM workspace — as soon as the object is
+# collected.  The finalizer touches no Dict (finalizers run at arbitrary allocation points); dead entries (a few words
+# each) are swept on the next lookup.  release!(g) does the same eagerly.
+mutable struct _DeviceSide
+    key::WeakRef
+    ctx::GPSLCHip.Ctx
+    pack::Union{GPSLCHip.Pack,Nothing}
+end
+const _GPSLC_DEVICE = Dict{UInt,_DeviceSide}()
+
+function _device_side(g::GPSLCObject)
+    ps = g.posteriorSamples
+    filter!(kv -> kv.second.key.value !== nothing, _GPSLC_DEVICE)
+    d = get(_GPSLC_DEVICE, objectid(ps), nothing)
+    if d === nothing || d.key.value !== ps || d.ctx.h == C_NULL
         nX = g.X === nothing ? 0 : getNX(g)
         nU = getNU(g) === nothing ? 0 : getNU(g)
         c = GPSLCHip.Ctx(getN(g), nX, nU)
         GPSLCHip.set_data!(c, g.X, g.T, g.Y)           # Bool treatments become 0.0 / 1.0 here
-        c
+        d = _DeviceSide(WeakRef(ps), c, nothing)
+        _GPSLC_DEVICE[objectid(ps)] = d
+        finalizer(_ -> GPSLCHip.destroy!(c), ps)
     end
+    d
 end
+
+"""release!(g): free g's device context and cached posterior pack now (otherwise: when g is garbage-collected)."""
+function release!(g::GPSLCObject)
+    d = pop!(_GPSLC_DEVICE, objectid(g.posteriorSamples), nothing)
+    d === nothing || GPSLCHip.destroy!(d.ctx)
+    nothing
+end
+
+"""ctx(g): the device context holding g.X, g.T, g.Y (src/types.jl:249-258), created on first use."""
+ctx(g::GPSLCObject) = _device_side(g).ctx
 
 """posterior_pack(g): extractParameters (src/utils.jl:92-124) for i in nBurnIn:stepSize:nOuter
 (src/estimation.jl:72, 78 — the burn-in index itself included), stacked along a trailing sample axis."""
 function posterior_pack(g::GPSLCObject)
-    get!(_GPSLC_PACK, g) do
+    d = _device_side(g)
+    if d.pack === nothing
         idx = g.hyperparams.nBurnIn:g.hyperparams.stepSize:g.hyperparams.nOuter
         ps = [extractParameters(g, i) for i in idx]            # (uyLS, xyLS, tyLS, yNoise, yScale, U)
         hasU, hasX = ps[1][1] !== nothing, ps[1][2] !== nothing
-        GPSLCHip.Pack(hasU ? cat((Float64.(p[6]) for p in ps)...; dims=3) : nothing,
-                      hasU ? reduce(hcat, (Float64.(p[1]) for p in ps)) : nothing,
-                      hasX ? reduce(hcat, (Float64.(vec(p[2])) for p in ps)) : nothing,
-                      Float64[p[3] for p in ps], Float64[p[4] for p in ps], Float64[p[5] for p in ps])
+        d.pack = GPSLCHip.Pack(hasU ? cat((_umat(p[6]) for p in ps)...; dims=3) : nothing,
+                               hasU ? reduce(hcat, [Float64.(p[1]) for p in ps]) : nothing,
+                               hasX ? reduce(hcat, [Float64.(vec(p[2])) for p in ps]) : nothing,
+                               Float64[p[3] for p in ps], Float64[p[4] for p in ps], Float64[p[5] for p in ps])
     end
+    d.pack::GPSLCHip.Pack
 end
-
-_ls(LS::Number) = Float64[LS]
-_ls(LS) = GPSLCHip.f64(vec(collect(LS)))
-_mat(X::AbstractMatrix) = GPSLCHip.f64(X)
-_mat(X::AbstractVector) = reshape(GPSLCHip.f64(X), :, 1)
 
 # ---- src/kernel.jl ------------------------------------------------------------------------------------------------
 function rbfKernelLogScalar(Xi::SupportedRBFVector, Xiprime::SupportedRBFVector, LS::SupportedRBFLengthscale)   # :13-19
@@ -423,10 +542,7 @@ end
 
 function rbfKernelLog(X1::SupportedRBFData, X2::SupportedRBFData, LS::SupportedRBFLengthscale)                  # :34-42
     @assert size(X1) == size(X2) "X1 and X2 are different sizes!"
-    # Vector{Vector}: individual i is X1[i]; stack the individuals as rows
-    A = permutedims(reduce(hcat, (GPSLCHip.f64(collect(x)) for x in X1)))
-    B = permutedims(reduce(hcat, (GPSLCHip.f64(collect(x)) for x in X2)))
-    GPSLCHip.rbf_log(GPSLCHip.kctx(), Matrix{Float64}(A), Matrix{Float64}(B), _ls(LS))
+    GPSLCHip.rbf_log(GPSLCHip.kctx(), _umat(X1), _umat(X2), _ls(LS))     # Vector{Vector}: individual i is X1[i]
 end
 
 function processCov(logCov::Union{Float64,Array{Float64}}, scale::Union{Float64,Array{Float64}}, noise::Float64)  # :53-55
@@ -442,10 +558,10 @@ end
 # ---- src/likelihood.jl: the four methods differ only in which of U / X are `nothing` ------------------------------
 function _likelihood_blocks(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y, doT)
     n = size(Y, 1)
-    c = GPSLCHip.Ctx(n, X === nothing ? 0 : size(X, 2), U === nothing ? 0 : size(U, 2))
+    Um = _umat(U)
+    c = GPSLCHip.dctx(n, X === nothing ? 0 : size(X, 2), _ncols(Um))
     GPSLCHip.set_data!(c, X, T, Y)
-    b = GPSLCHip.likelihood_distribution(c, U, uyLS, xyLS, tyLS, yScale, yNoise, Float64(doT))
-    GPSLCHip.destroy!(c)
+    b = GPSLCHip.likelihood_distribution(c, Um, uyLS, xyLS, tyLS, yScale, yNoise, _dot(doT))
     Y, b[1], b[2], b[3], b[4], b[5], b[6], b[7]        # Y, CovWW, CovWWs, CovWWp, CovC11, CovC12, CovC21, CovC22 (:51)
 end
 
@@ -485,14 +601,14 @@ function conditionalITE(uyLS::Union{Vector{Float64},Nothing}, xyLS::Union{Array{
                         yNoise::Float64, yScale::Float64, U::Union{Confounders,Nothing}, X::Union{Covariates,Nothing},
                         T::Treatment, Y::Outcome, doT::Intervention)                                              # :36-50
     n = size(Y, 1)
-    c = GPSLCHip.Ctx(n, X === nothing ? 0 : size(X, 2), U === nothing ? 0 : size(U, 2))
+    Um = _umat(U)
+    c = GPSLCHip.dctx(n, X === nothing ? 0 : size(X, 2), _ncols(Um))
     GPSLCHip.set_data!(c, X, T, Y)
-    p = GPSLCHip.Pack(U === nothing ? nothing : reshape(GPSLCHip.f64(U), n, :, 1),
+    p = GPSLCHip.Pack(Um === nothing ? nothing : reshape(Um, n, :, 1),
                       uyLS === nothing ? nothing : reshape(copy(uyLS), :, 1),
                       xyLS === nothing ? nothing : reshape(GPSLCHip.f64(vec(xyLS)), :, 1),
                       [tyLS], [yNoise], [yScale])
-    M, Cv = GPSLCHip.ite_distributions(c, p, Float64(doT), 0.0)          # CovITE itself: the jitter is ITEDistributions' (:82)
-    GPSLCHip.destroy!(c)
+    M, Cv = GPSLCHip.ite_distributions(c, p, _dot(doT), 0.0)             # CovITE itself: the jitter is ITEDistributions' (:82)
     M[1, :], Cv[1, :, :]
 end
 
@@ -502,25 +618,40 @@ function conditionalITE(g::GPSLCObject, psindex::Int64, doT::Intervention)      
 end
 
 function ITEDistributions(g::GPSLCObject, doT::Intervention)                                                       # :66-86
-    GPSLCHip.ite_distributions(ctx(g), posterior_pack(g), Float64(doT), g.hyperparams.predictionCovarianceNoise)
+    GPSLCHip.ite_distributions(ctx(g), posterior_pack(g), _dot(doT), g.hyperparams.predictionCovarianceNoise)
 end
 
 function SATEDistributions(g::GPSLCObject, doT::Intervention)                                                      # :127-140
-    mS, vS, _, _ = GPSLCHip.predict(ctx(g), posterior_pack(g), [Float64(doT)], g.hyperparams.predictionCovarianceNoise)
+    mS, vS, _, _ = GPSLCHip.predict(ctx(g), posterior_pack(g), [_dot(doT)], g.hyperparams.predictionCovarianceNoise)
     mS[:, 1], vS[:, 1]          # O(N^2) per posterior sample: the N x N covariance is never formed
 end
 
 # ---- src/driver.jl ------------------------------------------------------------------------------------------------
-function sampleITE(g::GPSLCObject, doT::Intervention; samplesPerPosterior::Int64=10)                               # :86-89
+# Where the standard normals of the draws come from.  `seed = nothing` (default): Julia's global RNG draws them on the
+# host, n x spp x S x L, exactly the stream Gen.mvnormal would consume (src/estimation.jl:105) — as long as that tensor
+# stays under _HOST_NORMALS_MAX bytes; beyond (BASELINE config 4: 4096 x 10 x 8192 x 64 doubles = 172 GB) ONE UInt64 is
+# drawn from the global RNG and seeds the library's Philox4x32-10 stream on the device (DESIGN.md §5), so Random.seed!
+# still determines the result.  `seed = k`: the Philox stream with that seed, no host tensor at all.
+const _HOST_NORMALS_MAX = 2^31
+function _normals(n, spp, S, L, seed)
+    seed === nothing || return (UInt64(seed), nothing)
+    8 * n * spp * S * L > _HOST_NORMALS_MAX && return (rand(Random.default_rng(), UInt64), nothing)
+    (UInt64(0), randn(n, spp, S, L))
+end
+
+function sampleITE(g::GPSLCObject, doT::Intervention; samplesPerPosterior::Int64=10,
+                   seed::Union{Nothing,Integer}=nothing)                                                           # :86-89
     n, S = getN(g), getNumPosteriorSamples(g)
-    z = randn(n, samplesPerPosterior, S, 1)                               # Julia's global RNG, as Gen.mvnormal would
-    _, _, _, ite = GPSLCHip.predict(ctx(g), posterior_pack(g), [Float64(doT)], g.hyperparams.predictionCovarianceNoise;
-                                    spp=samplesPerPosterior, z=z, want_draws=true)
+    sd, z = _normals(n, samplesPerPosterior, S, 1, seed)
+    _, _, _, ite = GPSLCHip.predict(ctx(g), posterior_pack(g), [_dot(doT)], g.hyperparams.predictionCovarianceNoise;
+                                    spp=samplesPerPosterior, seed=sd, z=z, want_draws=true)
     ite[1, :, :]                                                          # n x (S * spp), sample outer / draw inner (:100-107)
 end
 
-function sampleSATE(g::GPSLCObject, doT::Intervention; samplesPerPosterior::Int64=10)                              # :108-111
+function sampleSATE(g::GPSLCObject, doT::Intervention; samplesPerPosterior::Int64=10,
+                    seed::Union{Nothing,Integer}=nothing)                                                          # :108-111
     MeanSATEs, VarSATEs = SATEDistributions(g, doT)
+    seed === nothing || return GPSLCHip.sate_samples(MeanSATEs, VarSATEs, samplesPerPosterior; seed=UInt64(seed))
     z = randn(length(MeanSATEs) * samplesPerPosterior)
     GPSLCHip.sate_samples(MeanSATEs, VarSATEs, samplesPerPosterior; z=z)  # normal(mean, var): variance as sigma (:159)
 end
@@ -537,55 +668,111 @@ end
 
 # ---- src/prediction.jl --------------------------------------------------------------------------------------------
 function predictCounterfactualEffects(g::GPSLCObject, nSamplesPerMixture::Int64; fidelity::Int64=100,
-                                      minDoT=min(g.T...), maxDoT=max(g.T...))                                      # :23-36
+                                      minDoT=min(g.T...), maxDoT=max(g.T...),
+                                      seed::Union{Nothing,Integer}=nothing)                                        # :23-36
     delta = abs(maxDoT - minDoT)
     step = delta / fidelity
     doTrange = minDoT:step:maxDoT                                          # :24-28
     L, n, S = length(doTrange), getN(g), getNumPosteriorSamples(g)
-    z = randn(n, nSamplesPerMixture, S, L)
+    sd, z = _normals(n, nSamplesPerMixture, S, L, seed)
     # one factorisation of A per posterior sample, shared by its L levels; `ite` comes back in the reference's
     # layout (L x n x S*spp, level index fastest)
     _, _, _, ite = GPSLCHip.predict(ctx(g), posterior_pack(g), Float64.(collect(doTrange)),
-                                    g.hyperparams.predictionCovarianceNoise; spp=nSamplesPerMixture, z=z, want_draws=true)
+                                    g.hyperparams.predictionCovarianceNoise; spp=nSamplesPerMixture, seed=sd, z=z,
+                                    want_draws=true)
     return ite, doTrange
 end
 
-# ---- src/model_likelihood.jl: the :Y node keeps its address and value type; only the distribution object changes ----
+# ---- src/model_likelihood.jl, src/model_prior.jl: the Gaussian nodes of the Gen models ------------------------------
+# Every node keeps its ADDRESS and its VALUE TYPE (Vector{Float64}); only the distribution object inside @trace changes,
+# so src/inference.jl (Gen.mh on the addresses of src/proposal.jl:8-22, elliptical_slice on :U => k => :U and :logitT)
+# runs unchanged and scores these nodes on the GPU.  Three distributions, one per node kind:
+#   HipGPNormal   N(0, scale exp.(rbfKernelLog(F, F, ls)) + noise I)   :X => k => :X, :T, :logitT (and :Y)
+#   HipYNormal    the :Y node with the data set's X / T taken from a Ctx (no feature block to assemble per call)
+#   HipMvNormal   N(0, covscale * cov) for a dense, constant cov         :U => u => :U (cov = SigmaU)
+# Replacement text for the @gen bodies, line for line:
+#   generateU (src/model_prior.jl:27-30), mapped by generateUfromSigmaU (src/model_likelihood.jl:4-10):
+#       @gen function generateU(SigmaU::Matrix{Float64}, uNoise::Float64, n::Int64)::Vector{Float64}
+#           @trace(hip_mv_normal(SigmaU, uNoise), :U)
+#       end
+#       U = @trace(MappedGenerateU(fill(SigmaU, nU), fill(uNoise, nU), fill(n, nU)), :U)      # no SigmaU * uNoise per call
+#   generateXfromU (src/model_likelihood.jl:13-22), loop body for k:
+#       F, ls = _features(U => uxLS[k, :])
+#       X[:, k] = @trace(hip_gp_normal(F, ls, xScale[k], xNoise[k]), :X => k => :X)
+#   generateRealTfromUX / U / X (:36-44, :57-62, :77-83)  —  binary: address :logitT (:25-33, :47-54, :65-74):
+#       F, ls = _features(U => utLS, X => xtLS)
+#       T = @trace(hip_gp_normal(F, ls, tScale, tNoise), :T)
+#   generateYfromUXT / UT / XT / T (:83-120):
+#       F, ls = _features(U => uyLS, X => xyLS, T => tyLS)
+#       Y = @trace(hip_gp_normal(F, ls, yScale, yNoise), :Y)
+#     or, with the data set's context:   Y = @trace(hip_y_normal(c, U, X, uyLS, xyLS, tyLS, yScale, yNoise), :Y)
+function _register_continuous(D)                  # Gen.is_discrete is part of the Distribution interface where it exists
+    if isdefined(Gen, :is_discrete)
+        @eval Gen.is_discrete(::$D) = false
+    end
+    nothing
+end
+
+struct HipGPNormal <: Gen.Distribution{Vector{Float64}} end
+const hip_gp_normal = HipGPNormal()
+(d::HipGPNormal)(args...) = Gen.random(d, args...)
+
+function Gen.logpdf(::HipGPNormal, x::AbstractVector{<:Real}, F::Matrix{Float64}, ls::Vector{Float64}, scale::Float64,
+                    noise::Float64)
+    GPSLCHip.gp_score(GPSLCHip.nctx(length(x)), F, ls, scale, noise, GPSLCHip.f64(x))
+end
+
+function Gen.random(::HipGPNormal, F::Matrix{Float64}, ls::Vector{Float64}, scale::Float64, noise::Float64)
+    n = size(F, 1)
+    n <= 640 && return GPSLCHip.draw(GPSLCHip.nctx(n), F, ls, scale, noise, randn(n))
+    # beyond the single-launch node kernels: Gram matrix from the GPU, factor on the host (prior draws are rare: once per
+    # `generate`, src/inference.jl:20)
+    K = processCov(GPSLCHip.rbf_log(GPSLCHip.kctx(), F, F, ls), scale, noise)
+    LinearAlgebra.cholesky(LinearAlgebra.Symmetric(K)).L * randn(n)
+end
+Gen.has_output_grad(::HipGPNormal) = false
+Gen.has_argument_grads(::HipGPNormal) = ntuple(_ -> false, 4)              # F, ls, scale, noise
+Gen.logpdf_grad(::HipGPNormal, x, args...) = ntuple(_ -> nothing, 5)       # output + 4 arguments
+_register_continuous(HipGPNormal)
+
+struct HipMvNormal <: Gen.Distribution{Vector{Float64}} end
+const hip_mv_normal = HipMvNormal()
+(d::HipMvNormal)(args...) = Gen.random(d, args...)
+
+function Gen.logpdf(::HipMvNormal, x::AbstractVector{<:Real}, cov::Matrix{Float64}, covscale::Float64)
+    GPSLCHip.mvn_score(GPSLCHip.nctx(length(x)), cov, covscale, GPSLCHip.f64(x))
+end
+
+function Gen.random(::HipMvNormal, cov::Matrix{Float64}, covscale::Float64)
+    c = GPSLCHip.nctx(size(cov, 1))
+    if c.cov !== cov || c.cov_chol === nothing
+        c.cov !== cov && GPSLCHip.mvn_logpdf(c, cov, nothing, nothing)
+        c.cov, c.cov_chol = cov, LinearAlgebra.cholesky(LinearAlgebra.Symmetric(cov)).L
+    end
+    sqrt(covscale) * (c.cov_chol * randn(size(cov, 1)))
+end
+Gen.has_output_grad(::HipMvNormal) = false
+Gen.has_argument_grads(::HipMvNormal) = ntuple(_ -> false, 2)              # cov, covscale
+Gen.logpdf_grad(::HipMvNormal, x, args...) = ntuple(_ -> nothing, 3)       # output + 2 arguments
+_register_continuous(HipMvNormal)
+
 struct HipYNormal <: Gen.Distribution{Vector{Float64}} end
 const hip_y_normal = HipYNormal()
+(d::HipYNormal)(args...) = Gen.random(d, args...)
 
-function Gen.logpdf(::HipYNormal, y::Vector{Float64}, c::GPSLCHip.Ctx, U, X, uyLS, xyLS, tyLS::Float64,
+function Gen.logpdf(::HipYNormal, y::AbstractVector{<:Real}, c::GPSLCHip.Ctx, U, X, uyLS, xyLS, tyLS::Float64,
                     yScale::Float64, yNoise::Float64)
     # y = the value Gen is scoring (Y_or_null); X = the trace's :X => k => :X values (X_or_null) or nothing
-    GPSLCHip.y_logpdf(c, 1, U, X, y, uyLS, xyLS, [tyLS], [yScale], [yNoise])[1]
+    GPSLCHip.y_logpdf(c, 1, _umat(U), X, GPSLCHip.f64(y), uyLS, xyLS, [tyLS], [yScale], [yNoise])[1]
 end
 
 function Gen.random(::HipYNormal, c::GPSLCHip.Ctx, U, X, uyLS, xyLS, tyLS::Float64, yScale::Float64, yNoise::Float64)
-    # prior sampling only (generate without a constraint on :Y): chol(Ycov) * randn through the node-draw entry point,
-    # F = [U | X | T] with the data set's treatment column (n <= 640: the sizes the single-launch node kernels cover)
+    # prior sampling only (generate without a constraint on :Y): F = [U | X | T] with the data set's treatment column
     Xh, Th, _ = c.data
-    Xuse = X === nothing ? Xh : X
-    cols = Matrix{Float64}[]
-    ls = Float64[]
-    if U !== nothing
-        push!(cols, _mat(U))
-        append!(ls, uyLS)
-    end
-    if Xuse !== nothing
-        push!(cols, _mat(Xuse))
-        append!(ls, vec(xyLS))
-    end
-    push!(cols, _mat(Th))
-    push!(ls, tyLS)
-    F = reduce(hcat, cols)
-    z = randn(c.n)
-    y = GC.@preserve F ls z begin
-        node = GPSLCHip.GPSLCNode(size(F, 2), 0, pointer(F), pointer(ls), yScale, yNoise, pointer(z))
-        GPSLCHip.nodes_draw(c, [node])
-    end
-    y[:, 1]
+    F, ls = _features(_umat(U) => uyLS, (X === nothing ? Xh : X) => xyLS, Th => tyLS)
+    Gen.random(hip_gp_normal, F, ls, yScale, yNoise)
 end
 Gen.has_output_grad(::HipYNormal) = false
-Gen.has_argument_grads(::HipYNormal) = ntuple(_ -> false, 9)
-Gen.logpdf_grad(::HipYNormal, y, args...) = ntuple(_ -> nothing, 10)
-# generateYfromUXT (src/model_likelihood.jl:83-91):   Y = @trace(hip_y_normal(c, U, X, uyLS, xyLS, tyLS, yScale, yNoise), :Y)
+Gen.has_argument_grads(::HipYNormal) = ntuple(_ -> false, 8)               # c, U, X, uyLS, xyLS, tyLS, yScale, yNoise
+Gen.logpdf_grad(::HipYNormal, y, args...) = ntuple(_ -> nothing, 9)        # output + 8 arguments
+_register_continuous(HipYNormal)

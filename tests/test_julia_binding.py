@@ -142,7 +142,9 @@ def test_struct_layouts_mirror_the_header():
 def test_the_shim_defines_what_its_method_bodies_use():
     src = julia_source()
     for needle in (
-        "const KCTX", "function kctx()", "function ctx(g::GPSLCObject)", "function posterior_pack(g::GPSLCObject)",
+        "const KCTX", "function kctx()", "ctx(g::GPSLCObject) = _device_side(g).ctx",
+        "function posterior_pack(g::GPSLCObject)", "function _device_side(g::GPSLCObject)",
+        "function release!(g::GPSLCObject)", "function dctx(n::Integer, nX::Integer, nU::Integer)",
         "function rbfKernelLogScalar(Xi::SupportedRBFVector",
         "function rbfKernelLog(X1::SupportedRBFMatrix, X2::SupportedRBFMatrix",
         "function rbfKernelLog(X1::SupportedRBFData, X2::SupportedRBFData",          # src/kernel.jl:34-42
@@ -188,3 +190,206 @@ def test_block_structure_balances():
                 opens += 1
     assert depth == 0
     assert opens == ends, (opens, ends)
+
+
+# ---- round 4: the defects a reader found that the type-tuple check cannot see --------
+def _part2():
+    src = julia_source()
+    return src[src.index("end # module GPSLCHip"):]
+
+
+def _function_blocks(src):
+    """{signature line: body} of every top-level `function ... end` block (column-0 `function`, column-0 `end`)."""
+    out, lines, i = [], src.splitlines(), 0
+    while i < len(lines):
+        if lines[i].startswith("function "):
+            j = i
+            while not lines[j].startswith("end"):
+                j += 1
+            blk = "\n".join(lines[i:j + 1])
+            # the signature runs to the first line whose parentheses balance
+            depth, k = 0, i
+            while True:
+                depth += lines[k].count("(") - lines[k].count(")")
+                if depth == 0:
+                    break
+                k += 1
+            out.append(("\n".join(lines[i:k + 1]), "\n".join(lines[k + 1:j])))
+            i = j
+        i += 1
+    return out
+
+
+def _split_top(argstr):
+    parts, depth, cur = [], 0, ""
+    for ch in argstr:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur.strip())
+    return parts
+
+
+def _params(sig):
+    inner = sig[sig.index("(") + 1:sig.rindex(")")]
+    pos = inner.split(";")[0] if ";" in inner else inner
+    return _split_top(pos)
+
+
+DISTRIBUTIONS = ("HipYNormal", "HipGPNormal", "HipMvNormal")
+
+
+def test_gen_distribution_arities_follow_the_logpdf_signature():
+    """Gen's interface: logpdf(dist, value, args...), random(dist, args...), has_argument_grads -> one Bool per arg,
+    logpdf_grad -> (value grad, one per arg).  Round 3 shipped 9 / 10 for a distribution with 8 arguments."""
+    src = _part2()
+    blocks = _function_blocks(src)
+    for D in DISTRIBUTIONS:
+        lp = [sig for sig, _ in blocks if sig.startswith(f"function Gen.logpdf(::{D},")]
+        rd = [sig for sig, _ in blocks if sig.startswith(f"function Gen.random(::{D},")]
+        assert len(lp) == 1 and len(rd) == 1, D
+        nargs = len(_params(lp[0])) - 2                      # minus the distribution and the value
+        assert len(_params(rd[0])) - 1 == nargs, (D, "random takes the same arguments as logpdf, without the value")
+        m = re.search(r"Gen\.has_argument_grads\(::" + D + r"\) = ntuple\(_ -> false, (\d+)\)", src)
+        g = re.search(r"Gen\.logpdf_grad\(::" + D + r", \w+, args\.\.\.\) = ntuple\(_ -> nothing, (\d+)\)", src)
+        assert m and g, D
+        assert int(m.group(1)) == nargs, (D, m.group(1), nargs)
+        assert int(g.group(1)) == nargs + 1, (D, g.group(1), nargs + 1)
+        for needle in (f"struct {D} <: Gen.Distribution{{Vector{{Float64}}}} end", f"Gen.has_output_grad(::{D}) = false",
+                       f"(d::{D})(args...) = Gen.random(d, args...)", f"_register_continuous({D})"):
+            assert needle in src, needle
+
+
+def test_one_distribution_per_node_kind_with_its_trace_replacement_text():
+    """next-1's reference-side half: :U => u => :U (src/model_likelihood.jl:4-10), :X => k => :X (:13-22), :T / :logitT
+    (:25-80), :Y (:83-120) — each has a distribution and the line that replaces the @gen body's @trace."""
+    src = _part2()
+    for needle in ("@trace(hip_mv_normal(SigmaU, uNoise), :U)",
+                   "@trace(hip_gp_normal(F, ls, xScale[k], xNoise[k]), :X => k => :X)",
+                   "@trace(hip_gp_normal(F, ls, tScale, tNoise), :T)", ":logitT",
+                   "@trace(hip_gp_normal(F, ls, yScale, yNoise), :Y)",
+                   "@trace(hip_y_normal(c, U, X, uyLS, xyLS, tyLS, yScale, yNoise), :Y)",
+                   "_features(U => utLS, X => xtLS)", "_features(U => uyLS, X => xyLS, T => tyLS)"):
+        assert needle in src, needle
+    module = julia_source()
+    for helper in ("function gp_score(c::Ctx", "function draw(c::Ctx", "function mvn_score(c::Ctx"):
+        assert helper in module, helper
+
+
+def test_every_U_goes_through_umat():
+    """`Confounders` includes nested vectors — the reference's own estimation tests pass U = [[1.0]]
+    (test/test_data.jl:42) — so no function of part 2 may convert a U itself or read nU off size(U, 2)."""
+    src = _strip(_part2())                      # code only: the comments explain what not to do
+    assert "size(U, 2)" not in src
+    outside = "\n".join(l for l in src.splitlines() if not l.startswith("_umat("))     # _umat itself converts
+    assert not re.search(r"f64\(U\)", outside)
+    for form in ("_umat(::Nothing)", "_umat(U::AbstractMatrix{<:Real})", "_umat(U::AbstractVector{<:Real})",
+                 "_umat(U::AbstractVector{<:AbstractVector})"):
+        assert form in src, form
+    forwards = ("_likelihood_blocks(", "conditionalITE(", "hip_y_normal(")
+    checked = 0
+    for sig, body in _function_blocks(src):
+        if sig.startswith("function _umat"):
+            continue
+        if not any(re.match(r"U(::|$)", prm) for prm in _params(sig)):
+            continue
+        checked += 1
+        if "_umat(U)" in body:
+            continue
+        # otherwise U may only be asserted on (size(U, 1): the same for every form) or forwarded whole
+        for line in body.splitlines():
+            if re.search(r"\bU\b", line):
+                assert "size(U, 1)" in line or any(f in line for f in forwards), (sig.splitlines()[0], line)
+    assert checked >= 8                       # 4 likelihoodDistribution methods, _likelihood_blocks, conditionalITE, 2 x HipYNormal
+
+
+def test_device_side_cache_is_weak_and_releasable():
+    src = _part2()
+    assert "IdDict" not in src                                     # round 3: strong IdDicts keyed by g, never emptied
+    blk = dict((sig.splitlines()[0], body) for sig, body in _function_blocks(src))
+    body = blk["function _device_side(g::GPSLCObject)"]
+    assert "WeakRef(ps)" in body and "finalizer(" in body and "destroy!" in body and "filter!(" in body
+    assert "GPSLCHip.destroy!(d.ctx)" in blk["function release!(g::GPSLCObject)"]
+    # no context is created and destroyed per call inside the parameter-level functions
+    for sig, body in _function_blocks(src):
+        if sig.startswith(("function conditionalITE(uyLS", "function _likelihood_blocks(")):
+            assert "GPSLCHip.dctx(" in body and "GPSLCHip.Ctx(" not in body and "destroy!" not in body, sig
+
+
+def test_draw_entry_points_offer_the_seeded_path():
+    """predictCounterfactualEffects at BASELINE config 4 would allocate randn(4096, 10, 8192, 64) = 172 GB on the host."""
+    src = _part2()
+    for sig, body in _function_blocks(src):
+        if sig.startswith(("function sampleITE(g", "function predictCounterfactualEffects(g", "function sampleSATE(g")):
+            assert "seed::Union{Nothing,Integer}=nothing" in sig, sig
+        if sig.startswith(("function sampleITE(g", "function predictCounterfactualEffects(g")):
+            assert "_normals(" in body and "seed=sd" in body and "randn(" not in body, sig
+    body = dict((s_.splitlines()[0], b) for s_, b in _function_blocks(src))["function _normals(n, spp, S, L, seed)"]
+    assert "_HOST_NORMALS_MAX" in body and "rand(Random.default_rng(), UInt64)" in body
+
+
+def header_param_names():
+    txt = open(_lib.HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"typedef struct \w+ \{.*?\} \w+;", "", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(gpslc_\w+)\s*\(([^)]*)\)\s*;", txt):
+        args = m.group(2).strip()
+        out[m.group(1)] = [] if args in ("", "void") else [re.findall(r"\w+", a)[-1] for a in args.split(",")]
+    return out
+
+
+# what the wrappers call their marshalled copies of the header's parameters
+JL_ALIASES = {"uf": "u", "xf": "x", "yf": "y", "tf": "t", "uy": "uyls", "xy": "xyls", "ty": "tyls", "yn": "ynoise",
+              "ys": "yscale", "ms": "meansate", "vs": "varsate", "mi": "meanite", "dr": "ite_draws", "zf": "z",
+              "m": "meanites", "cv": "covites", "cf": "cov", "sf": "covscale", "x1": "x1", "x2": "x2", "lp": "logpdf",
+              "out": None, "h": None, "r": None, "l": None, "fl": None, "st": None}
+SAME_TYPED = {"u", "uyls", "xyls", "tyls", "yscale", "ynoise", "x", "t", "y", "dot", "meansate", "varsate", "meanite",
+              "ite_draws", "meanites", "covites", "mean", "lower", "upper", "ls", "f", "target", "scale", "noise",
+              "cov", "covscale", "z", "x1", "x2", "logcov", "samples", "draws"}
+
+
+def _canon_expr(e):
+    e = re.sub(r"\b(?:pointer|ptr|Ref)\(", "", e).rstrip(")")
+    e = re.sub(r"^(?:p|c)\.", "", e)
+    e = re.sub(r"\[\d+\]$", "", e)
+    e = e.split("?")[0].strip() if "?" in e else e
+    e = e.lower()
+    return JL_ALIASES.get(e, e)
+
+
+def test_ccall_arguments_follow_the_header_parameter_order_by_name():
+    """Same-typed pointer arguments (yNoise / yScale, mean / lower / upper, ...) cannot be told apart by the type tuple:
+    compare the NAME of the expression passed at each position with the header's parameter name."""
+    names = header_param_names()
+    src = julia_source()
+    seen = 0
+    for m in re.finditer(r"ccall\(\(:(\w+),\s*lib\),\s*\w+,\s*\(", src):
+        name = m.group(1)
+        i, depth = m.end(), 1                    # skip the type tuple
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        j, depth = i, 1                          # the ccall's own closing parenthesis
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[j], 0)
+            j += 1
+        exprs = _split_top(src[i:j - 1].lstrip(", \n"))
+        assert len(exprs) == len(names[name]), (name, exprs, names[name])
+        for e, pname in zip(exprs, names[name]):
+            want = re.sub(r"_or_null$", "", pname).lower()
+            if want not in SAME_TYPED:
+                continue
+            got = _canon_expr(e)
+            if got is None or got.startswith("blocks") or got == "c_null":
+                continue
+            assert got == want, f"{name}: `{e}` is passed where the header has `{pname}`"
+            seen += 1
+    assert seen >= 100
