@@ -394,6 +394,33 @@ def run_config(gp, synth, np, torch, dev, local_rank, n, D, K, S, L, binary_t, f
     return rec
 
 
+def write_bench_pack(path, X, T, Y, post, binary_t):
+    """The data set and the posterior samples of ALL ranks as one posterior pack (gpslc_pack_save): generated once per
+    node by rank 0, every rank then loads only its own block of samples (gpslc_pack_load(path, s0, s1))."""
+    import numpy as np
+    from causalgpslc_jl_amd import _lib
+    from causalgpslc_jl_amd.api import _p
+    n = len(T)
+    nX = 0 if X is None else X.shape[1]
+    nU = 0 if post["U"] is None else post["U"].shape[1]
+    h = _lib.PackHeader(n, nX, nU, len(post["tyLS"]), 1 if binary_t else 0, 0)
+    for i, v in enumerate((nU if nU else -1.0, 0, 0, 0, 0, 1, 1e-10)):
+        h.hyper[i] = float(v)
+    arrs = [None if x is None else np.asfortranarray(x, dtype=np.float64)
+            for x in (X, T, Y, post["U"], post["uyLS"], post["xyLS"], post["tyLS"], post["yNoise"], post["yScale"])]
+    st = _lib.load().gpslc_pack_save(os.fsencode(path), C.byref(h), *[_p(x) for x in arrs])
+    if st != 0:
+        raise RuntimeError(f"gpslc_pack_save({path}): status {st}")
+
+
+def read_bench_pack(path, s0, s1):
+    """(X, T, Y, post) with the posterior samples [s0, s1) of the pack rank 0 wrote."""
+    from causalgpslc_jl_amd import pack
+    g = pack.loadGPSLCObject(path, samples=(s0, s1))
+    post = {"U": g.U, "uyLS": g.uyLS, "xyLS": g.xyLS, "tyLS": g.tyLS, "yNoise": g.yNoise, "yScale": g.yScale}
+    return g.X, g.T, g.Y, post
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -437,8 +464,24 @@ def main():
 
     n, D, K, L = a.n, a.d, a.nu, a.levels
     Sr = a.samples_per_step
-    X, T, Y, obj = synth.make_dataset(n, D, binary_t=a.binary_t)
-    post = synth.make_posterior(n, D, K, Sr, obj, seed=1234 + 17 * rank)   # every rank owns different samples
+    if world == 1:
+        X, T, Y, obj = synth.make_dataset(n, D, binary_t=a.binary_t)
+        post = synth.make_posterior(n, D, K, Sr, obj, seed=1234)
+    else:
+        # one data set and one posterior of Sr * world samples per NODE: rank 0 generates and writes a posterior pack, every
+        # rank loads its own contiguous block of samples — the partition of sharded.py (src/prediction.jl:30-33 over
+        # src/estimation.jl:78-84: the loop over posterior samples is what shards)
+        pack_path = os.path.join(os.environ.get("TMPDIR", "/tmp"),
+                                 f"gpslc_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.pack")
+        obj = None
+        if rank == 0:
+            X0, T0, Y0, obj = synth.make_dataset(n, D, binary_t=a.binary_t)
+            write_bench_pack(pack_path, X0, T0, Y0, synth.make_posterior(n, D, K, Sr * world, obj, seed=1234), a.binary_t)
+        dist.barrier()
+        X, T, Y, post = read_bench_pack(pack_path, rank * Sr, (rank + 1) * Sr)
+        dist.barrier()
+        if rank == 0:
+            os.remove(pack_path)
     doT = synth.levels(T, L)
 
     def to_dev(x):
@@ -623,19 +666,22 @@ def main():
             if not c4.get("parity", {}).get("ok", True):
                 rc = 4
         unit0, unit0_name = None, ""
-        if world == 1 and not a.no_cpu_baseline and not a.timing_only:
-            rec, ref, unit0 = cpu_baseline(n, D, K, a.cpu_units, X, T, Y, post, float(doT[0]))
+        if not a.no_cpu_baseline and not a.timing_only:
+            # N > 1: rank 0 times the CPU leg on ITS block of samples (fewer units, so the other ranks, parked at the
+            # barrier below, wait about 30 s); the line then carries cpu_baseline and sate_rel_err for every N
+            cpu_units = a.cpu_units if world == 1 else min(a.cpu_units, 2)
+            rec, ref, unit0 = cpu_baseline(n, D, K, cpu_units, X, T, Y, post, float(doT[0]))
             unit0_name = "literal CPU restatement (oracle.ite_distributions: src/estimation.jl:36-50, 82), fp64"
             out["cpu_baseline"] = rec
             # the metric's second half: this run's GPU results for the very units the CPU leg computed
             ms2, vs2 = ms_h.reshape(Sr, L, order="F"), vs_h.reshape(Sr, L, order="F")
-            em = max(abs(ms2[s, 0] - ref[s][0]) / abs(ref[s][0]) for s in range(a.cpu_units))
-            ev = max(abs(vs2[s, 0] - ref[s][1]) / abs(ref[s][1]) for s in range(a.cpu_units))
+            em = max(abs(ms2[s, 0] - ref[s][0]) / abs(ref[s][0]) for s in range(cpu_units))
+            ev = max(abs(vs2[s, 0] - ref[s][1]) / abs(ref[s][1]) for s in range(cpu_units))
             tol = 1e-4 if a.fp32_kernel else 1e-6
             ok = all(abs(ms2[s, 0] - ref[s][0]) <= tol * abs(ref[s][0]) + 1e-12 and
                      abs(vs2[s, 0] - ref[s][1]) <= tol * abs(ref[s][1]) + 1e-9 * float(post["yScale"][s])
-                     for s in range(a.cpu_units))
-            out["sate_rel_err"] = {"mean": em, "var": ev, "units": a.cpu_units, "tolerance": tol, "ok": ok,
+                     for s in range(cpu_units))
+            out["sate_rel_err"] = {"mean": em, "var": ev, "units": cpu_units, "tolerance": tol, "ok": ok,
                                    "reference": "literal CPU restatement (oracle.ite_distributions + conditional_sate: "
                                                 "src/estimation.jl:36-50, 82, 116-121), fp64, same inputs",
                                    "rule": "|dMean| <= tol |ref| + 1e-12 and |dVar| <= tol |ref| + 1e-9 yScale (SURVEY §8d)"}
@@ -665,6 +711,9 @@ def main():
                     "issue time per sample at 2.4 GHz, SQ_ACTIVE_INST_VALU of profiles/r03_pmc_gram.md and "
                     "r03_pmc_ite_mean.md): the MFMA-only ceiling ignores that both instruction classes use the same fp64 units")
             out["units"]["A"] = ua
+        if world > 1:
+            out["units"] = "N=1 only (units B / C and the unit-A ceilings are single-GPU measurements: run without --gpus)"
+            out["configs"] = "N=1 only (BASELINE configs[1] and configs[4] are timed on one GPU: run without --gpus)"
         if world == 1 and not a.no_configs and not a.timing_only:
             ctx.close()
             torch.cuda.empty_cache()

@@ -113,6 +113,7 @@ struct gpslc_ctx {
     bool binary_t = false;   // every treatment is exactly 0 or 1 (detected in gpslc_set_data)
     int max_batch = 0;   // 0 = auto
     int panel = 8;
+    int64_t ens_off = 0, ens_S = 0;   // gpslc_set_ensemble: placement of a call's samples for the Philox stream ids
     int nstreams = 1;   // chunks of one call alternate over this many HIP streams (2 buys ~1-2 %, see profiles/)
     std::vector<hipStream_t> streams;
     std::vector<Arena> arenas;     // one per stream slot
@@ -723,6 +724,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                         DrawArgs dr{};
                         dr.Lc = Cm; dr.n = n; dr.nt = nt; dr.s0 = s0 + g0; dr.S = io.S; dr.l = l0; dr.lc = lc; dr.L = L;
                         dr.spp = io.spp; dr.mean = meanITE; dr.z = io.z; dr.zgen = zgen; dr.seed = io.seed;
+                        dr.rs0 = dr.s0 + (c->ens_S > 0 ? c->ens_off : 0); dr.rS = c->ens_S > 0 ? c->ens_S : io.S;
                         if (L == 1) {     // the reference tensor directly: n x (S*spp), instance fastest
                             dr.out = io.ite_draws;
                             dr.obase = (long long)n * io.spp * (s0 + g0); dr.osb = (long long)n * io.spp; dr.osl = 0;
@@ -1118,6 +1120,15 @@ int gpslc_set_tuning(gpslc_ctx* c, int32_t max_batch, int32_t panel_tiles, int32
 }
 
 const char* gpslc_last_error(const gpslc_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int gpslc_set_ensemble(gpslc_ctx* c, int64_t sample_offset, int64_t S_total) {
+    if (!c) return -1;
+    if (sample_offset < 0) return -2;
+    if (S_total < 0 || (S_total > 0 && sample_offset >= S_total)) return -3;
+    c->ens_off = S_total > 0 ? sample_offset : 0;
+    c->ens_S = S_total;
+    return 0;
+}
 
 static int rbf_log_check(gpslc_ctx* c, const double* X1, const double* X2, int64_t n, int32_t d, const double* ls,
                          int32_t ls_len, double* out) {

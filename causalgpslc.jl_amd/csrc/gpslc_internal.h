@@ -206,6 +206,7 @@ struct DrawArgs {
     const double* z;      // caller's normals, n x spp x S x L, or null
     double* zgen;         // z == null: workspace [nbatch][spp][n] the library's Philox normals are generated into
     unsigned long long seed;
+    long long rs0, rS;    // Philox stream of batch element b: (rs0 + b / lc) + rS * (l + b % lc) (gpslc_set_ensemble)
     // element (instance i, sample offset sb = b / lc, level offset lb = b % lc, draw d) of this launch goes to
     // out[obase + sb*osb + lb*osl + i*osi + d*osd]: the reference tensor L x n x (S*spp) directly (L == 1), or the
     // level-sweep staging buffer [sample][level][d][i]

@@ -42,6 +42,8 @@ __device__ __forceinline__ double frag(const double* X, int ld, int rbase, int k
     return X[(kbase + 4 * kk + (lane >> 4)) * ld + rbase + (lane & 15)];
 }
 
+#ifdef GPSLC_DIAG   // version 1 (133 KiB square image, one workgroup per CU): measurement build only, for the A/B of
+                    // profiles/r02_ab_experiments.md; the production library compiles and launches version 2 alone
 __global__ __launch_bounds__(256) void diag_potrf_inv_kernel(TRef M, int k, double* inv,
                                                              long long inv_bstride, int* info,
                                                              int info_base) {
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(256) void diag_potrf_inv_kernel(TRef M, int k, doub
     }
 }
 
+#endif  // GPSLC_DIAG
 // ---------------------------------------------------------------------------------------
 // Version 2: the same arithmetic on a PACKED image — only the 36 lower 16 x 16 sub-blocks live in LDS
 // (72 KiB + one 2 KiB slot for the current inv(L_pp)), so TWO workgroups fit a CU.  The kernel is latency
@@ -330,20 +333,20 @@ __global__ __launch_bounds__(256, 2) void diag_potrf_inv_v2_kernel(TRef M, int k
 
 #define DIAG2_LDS_BYTES ((36 * 256 + 256) * 8)
 
-#define DIAG_LDS_BYTES ((GP_TS * DLD + NSB * SB * SB) * 8)
-
 void launch_diag(const TRef& M, int k, double* inv, long long inv_bstride, int* info,
                  int info_base, int nbatch, hipStream_t st) {
-    static DeviceOnce attr_set;
-    lds_opt_in(attr_set, (const void*)diag_potrf_inv_kernel, DIAG_LDS_BYTES);
-    static const int v1 = diag_env("GPSLC_DIAG_V1", 0) == 1 ? 1 : 0;
-    if (!v1) {
-        static DeviceOnce attr2;
-    lds_opt_in(attr2, (const void*)diag_potrf_inv_v2_kernel, DIAG2_LDS_BYTES);
-        hipLaunchKernelGGL(diag_potrf_inv_v2_kernel, dim3(nbatch), dim3(256), DIAG2_LDS_BYTES, st, M, k, inv,
+#ifdef GPSLC_DIAG
+#define DIAG_LDS_BYTES ((GP_TS * DLD + NSB * SB * SB) * 8)
+    if (diag_env("GPSLC_DIAG_V1", 0) == 1) {
+        static DeviceOnce attr_set;
+        lds_opt_in(attr_set, (const void*)diag_potrf_inv_kernel, DIAG_LDS_BYTES);
+        hipLaunchKernelGGL(diag_potrf_inv_kernel, dim3(nbatch), dim3(256), DIAG_LDS_BYTES, st, M, k, inv,
                            inv_bstride, info, info_base);
         return;
     }
-    hipLaunchKernelGGL(diag_potrf_inv_kernel, dim3(nbatch), dim3(256), DIAG_LDS_BYTES, st, M, k, inv,
+#endif
+    static DeviceOnce attr2;
+    lds_opt_in(attr2, (const void*)diag_potrf_inv_v2_kernel, DIAG2_LDS_BYTES);
+    hipLaunchKernelGGL(diag_potrf_inv_v2_kernel, dim3(nbatch), dim3(256), DIAG2_LDS_BYTES, st, M, k, inv,
                        inv_bstride, info, info_base);
 }

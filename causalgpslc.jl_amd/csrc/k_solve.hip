@@ -689,8 +689,8 @@ static void launch_draws_t(const DrawArgs& a, int nbatch, hipStream_t st) {
 void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st) {
     if (!a.z) {     // the library's own stream: every normal of the unit is generated exactly once
         const long long pairs = ((long long)a.n * a.spp + 1) / 2;
-        hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((pairs + 255) / 256), nbatch), dim3(256), 0, st, a.seed, a.s0,
-                           a.S, a.l, a.lc, (long long)a.n, a.spp, a.zgen);
+        hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((pairs + 255) / 256), nbatch), dim3(256), 0, st, a.seed, a.rs0,
+                           a.rS, a.l, a.lc, (long long)a.n, a.spp, a.zgen);
     }
     if (a.spp <= 16) launch_draws_t<1>(a, nbatch, st);
     else if (a.spp <= 32) launch_draws_t<2>(a, nbatch, st);

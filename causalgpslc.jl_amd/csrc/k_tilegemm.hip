@@ -440,7 +440,12 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
         if (GP_DBG_ON(g)) st0 = __builtin_amdgcn_s_memtime();
 
         d4 acc[2][8];
+#ifdef STRIP_NO_CLOAD      // timing-only A/B knob (make variant): accumulators zeroed, results are garbage
+        for (int n = 0; n < 8; ++n) { acc[0][n] = (d4){0.0, 0.0, 0.0, 0.0}; acc[1][n] = (d4){0.0, 0.0, 0.0, 0.0}; }
+        if (false) {
+#else
         if (live) {
+#endif
             const double* __restrict__ Cl = Ct + (lg * GP_TS + 32 * wave + li);
 #pragma unroll
             for (int n = 0; n < 8; ++n)
@@ -475,6 +480,31 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
                 if (!live) return;
                 const double* pa = lA + buf * OPER_LDS + frow_a;
                 const double* pb = lB + buf * OPER_LDS + frow_b;
+#ifdef STRIP_PIPE
+                double afn[2], bfn[8];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) afn[m] = pa[16 * m];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) bfn[n] = pb[16 * n];
+#pragma unroll
+                for (int ks = 0; ks < KS / 4; ++ks) {
+                    double af[2], bf[8];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) af[m] = afn[m];
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) bf[n] = bfn[n];
+                    if (ks + 1 < KS / 4) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) afn[m] = pa[(ks + 1) * 4 * LROW + 16 * m];
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) bfn[n] = pb[(ks + 1) * 4 * LROW + 16 * n];
+                    }
+#pragma unroll
+                    for (int n = 0; n < 8; ++n)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][n] = mfma_step<1>(bf[n], af[m], acc[m][n]);
+                }
+#else
 #pragma unroll
                 for (int ks = 0; ks < KS / 4; ++ks) {
                     double af[2], bf[8];
@@ -487,6 +517,7 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
 #pragma unroll
                         for (int m = 0; m < 2; ++m) acc[m][n] = mfma_step<1>(bf[n], af[m], acc[m][n]);
                 }
+#endif
             };
             gload(0, ra, rb);
             lstore(0, ra, rb);
@@ -756,7 +787,10 @@ static void launch_syrk_diag_t(const GemmArgs& g, unsigned grid, hipStream_t st)
 // carry_aug: the items also update the augmented-row tiles (short_row0, i0 + t) (live rows g.short_rows).
 void launch_syrk_diag(const GemmArgs& g, int carry_aug, hipStream_t st) {
     if (g.mi <= 0 || g.nbatch <= 0 || g.k1 <= g.k0) return;
-    const int slots = 2 * device_cus();
+    int slots = 2 * device_cus();
+#ifdef GPSLC_DIAG
+    slots = diag_env("GPSLC_GEMM_SLOTS", slots);
+#endif
     const long long Wk = (long long)g.mi * g.nbatch;
     const unsigned grid = (unsigned)(Wk < slots ? Wk : slots);
     const int mt = carry_aug ? (g.short_rows + 15) / 16 : 0;   // callers pass carry_aug only for mt <= 2

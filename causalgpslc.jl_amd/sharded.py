@@ -89,7 +89,7 @@ class ShardedResult:
     world: int
 
 
-def _hip_compute(g_local, doTs, dev_index, L, want_mean_ite, spp, seed, z_local):
+def _hip_compute(g_local, doTs, dev_index, L, want_mean_ite, spp, seed, z_local, placement=None):
     """Run the HIP path for this rank's block with every output left in HBM.  Returns device tensors
     (ms (S_r, L), vs (S_r, L), mi (n, S_r, L) | None, draws (L, n, S_r*spp) | None) — views of the library's
     column-major buffers, nothing copied."""
@@ -112,14 +112,25 @@ def _hip_compute(g_local, doTs, dev_index, L, want_mean_ite, spp, seed, z_local)
     dr = torch.empty(L * n * Sl * spp, dtype=torch.float64, device=dev) if spp > 0 else None
     dz = to_dev(z_local) if (spp > 0 and z_local is not None) else None
     torch.cuda.synchronize(dev)     # stream contract of the _dev entry points: inputs complete before the call
+    if placement is not None:       # (s0, S): this block's place in the whole ensemble, for the library's normals
+        ctx.set_ensemble(*placement)
     st = ctx.lib.gpslc_predict_dev(ctx.h, Sl, *[ptr(t) for t in packs], L, ptr(ddo),
                                    float(g_local.hyperparams.predictionCovarianceNoise), int(spp),
                                    int(seed) if dz is None else 0, ptr(dz),
                                    ptr(ms), ptr(vs), ptr(mi), ptr(dr))
+    if placement is not None:
+        ctx.set_ensemble(0, 0)
     ctx.check(st)
     return (ms.view(L, Sl).t(), vs.view(L, Sl).t(),
             None if not want_mean_ite else mi.view(L, Sl, n).permute(2, 1, 0),
             None if dr is None else dr.view(Sl * spp, n, L).permute(2, 1, 0))
+
+
+def _global_rank(group, group_rank):
+    """`root` is a rank OF THE GROUP everywhere in this module (it is compared with dist.get_rank(group)); torch's
+    gather wants the global rank as `dst`."""
+    import torch.distributed as dist
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
 
 
 def _collect(x_local, full_shape_of, pad_shape, axis, mode, world, rank, root, group, buf_dev, ranges, to_host):
@@ -138,7 +149,7 @@ def _collect(x_local, full_shape_of, pad_shape, axis, mode, world, rank, root, g
             send.narrow(axis, 0, x_local.shape[axis]).copy_(x_local)
         if mode == "root":
             recv = [torch.empty_like(send) for _ in range(world)] if rank == root else None
-            dist.gather(send, recv, dst=root, group=group)
+            dist.gather(send, recv, dst=_global_rank(group, root), group=group)
         else:
             recv = [torch.empty_like(send) for _ in range(world)]
             dist.all_gather(recv, send, group=group)
@@ -148,6 +159,7 @@ def _collect(x_local, full_shape_of, pad_shape, axis, mode, world, rank, root, g
         for r, (a, b) in enumerate(ranges):
             if b > a:
                 out.narrow(axis, a, b - a).copy_(recv[r].narrow(axis, 0, b - a))
+            recv[r] = None          # the padded block is not needed any more: the peak stays near one full tensor + blocks in flight
     if out is not None and to_host:
         out = out.cpu().numpy()
     return out
@@ -162,8 +174,9 @@ def predict_sharded_full(g, doTs: Sequence[float], group=None, device=None, comp
     ``g`` holds either all S posterior samples (every rank passes the same object; the rank's block is sliced
     out) or — with ``samples = (S, s0, s1)`` — only this rank's block [s0, s1) of a pack of S samples.
     Draws: ``z`` = the caller's standard normals (n, spp, S, L) for the WHOLE ensemble (each rank takes its block), or
-    None for the library's Philox normals seeded per rank (``seed + rank``: the library numbers a call's samples from
-    0, so a rank-independent seed would repeat the streams of rank 0 on every rank).
+    None for the library's Philox normals with ``seed``: every rank tells the library where its block sits in the
+    ensemble (``gpslc_set_ensemble(s0, S)``), so sample s draws from stream s + S*l whatever the number of ranks — the
+    draws of (seed, posterior pack) do not depend on the sharding (round 3 seeded ``seed + rank``: they did).
     ``compute(g_local, doTs)`` -> (ms, vs[, mi]) or, when draws are requested,
     ``compute(g_local, doTs, spp, z_local)`` -> (ms, vs, mi, draws (L, n, S_r*spp)): the CPU stand-in of the tests.
     """
@@ -213,7 +226,7 @@ def predict_sharded_full(g, doTs: Sequence[float], group=None, device=None, comp
             if local is not None and local.device != dev_index:
                 g_local = slice_object(local, 0, Sl, device=dev_index)
             ms, vs, mi_local, dr_local = _hip_compute(g_local, doTs, dev_index, L, want_mi, spp if want_draws else 0,
-                                                      seed + rank, z_local)
+                                                      seed, z_local, placement=(s0, S))
         else:
             res = compute(g_local, doTs, spp, z_local) if want_draws else compute(g_local, doTs)
             ms = torch.from_numpy(np.ascontiguousarray(res[0]))
@@ -240,7 +253,7 @@ def predict_sharded_full(g, doTs: Sequence[float], group=None, device=None, comp
             dist.all_gather(recv, send, group=group)
         else:
             recv = [torch.empty_like(send) for _ in range(world)] if rank == root else None
-            dist.gather(send, recv, dst=root, group=group)
+            dist.gather(send, recv, dst=_global_rank(group, root), group=group)
         if recv is not None:
             allb = torch.stack(recv).cpu().numpy()            # (world, blk, 2L)
             out_m = np.zeros((S, L))

@@ -70,6 +70,14 @@ int gpslc_set_data_dev(gpslc_ctx* ctx, const double* X, const double* T, const d
  * width of the blocked Cholesky, number of HIP streams chunks are spread over. */
 int gpslc_set_tuning(gpslc_ctx* ctx, int32_t max_batch, int32_t panel_tiles, int32_t n_streams);
 
+/* Placement of a call's posterior samples inside a larger ensemble, for the library's own normals (z_or_null == NULL):
+ * after gpslc_set_ensemble(ctx, s_off, S_total) sample s, level l of gpslc_predict[_dev] draws from the Philox stream
+ * (s_off + s) + S_total * l instead of s + S * l.  A rank of a sharded prediction that holds the samples [s0, s1) of
+ * S_total (the partition of the loop src/estimation.jl:78-84 under src/prediction.jl:30-33) sets (s0, S_total) and then
+ * generates exactly the normals a single-process call over all S_total samples generates for them — the result does not
+ * depend on the number of ranks.  S_total = 0 restores the default (offset 0, the call's own S). */
+int gpslc_set_ensemble(gpslc_ctx* ctx, int64_t sample_offset, int64_t S_total);
+
 const char* gpslc_last_error(const gpslc_ctx* ctx);
 
 /* ---- src/kernel.jl ------------------------------------------------------------------- */

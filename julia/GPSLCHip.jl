@@ -113,6 +113,11 @@ set_data_dev!(c::Ctx, X::Ptr{Float64}, T::Ptr{Float64}, Y::Ptr{Float64}) = check
 set_tuning!(c::Ctx; max_batch::Integer=0, panel_tiles::Integer=0, n_streams::Integer=0) = check(c,
     ccall((:gpslc_set_tuning, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Int32), c.h, max_batch, panel_tiles, n_streams))
 
+"""Placement of the next calls' posterior samples inside a larger ensemble (a rank's block [s0, s1) of S_total): the
+library's own normals then do not depend on how the ensemble is sharded.  S_total = 0 restores the default."""
+set_ensemble!(c::Ctx, sample_offset::Integer, S_total::Integer) = check(c,
+    ccall((:gpslc_set_ensemble, lib), Cint, (Ptr{Cvoid}, Int64, Int64), c.h, sample_offset, S_total))
+
 # ---- src/kernel.jl ----------------------------------------------------------------------------------------------
 function rbf_log(c::Ctx, X1::Array{Float64}, X2::Array{Float64}, ls::Vector{Float64})
     n, d = size(X1, 1), size(X1, 2)

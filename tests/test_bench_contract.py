@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -69,3 +71,45 @@ def test_committed_bench_line_carries_the_contract_keys():
     assert d["config4"]["levels"] == 64 and d["config4"]["parity"]["ok"]
     assert {"c2", "c5"} <= set(d["configs"]) and all(c["parity"]["ok"] for c in d["configs"].values())
     assert d["units"]["A"]["ceiling_shared_datapath_units_per_s"] < d["units"]["A"]["ceiling_units_per_s"]
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_line_carries_the_whole_contract():
+    """The N > 1 path of bench.py, end to end, on a one-GPU box: two ranks under torch.distributed.run share device 0 over
+    gloo (GPSLC_BENCH_REHEARSAL=1).  Rank 0 writes the node's posterior pack, every rank loads its own block, both timed
+    regions are sharded and gathered, rank 0 runs the CPU leg — and the ONE JSON line must carry what the N = 1 line
+    carries: roofline, cpu_baseline, sate_rel_err, config4.parity, with n_gpus = 2 and the rehearsal label.  (No scaling
+    figure is read off this: it checks the contract, not the speed.)"""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["GPSLC_BENCH_REHEARSAL"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "1", "--n", "640", "--d", "4", "--nu", "1", "--samples-per-step", "24", "--config4-levels", "8",
+           "--config4-steps", "1", "--cpu-units", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "REHEARSAL" in d["data"] and d["scaling"] == "weak"
+    for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype",
+              "config", "roofline", "cpu_baseline", "sate_rel_err", "config4", "units", "configs"):
+        assert k in d, k
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]) and 0 < d["roofline"]["frac"] <= 1
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["value"] > 0
+    assert d["sate_rel_err"]["ok"] and d["sate_rel_err"]["units"] == 2
+    assert d["config4"]["parity"]["ok"] and d["config4"]["levels"] == 8
+    assert "2 rank(s)" in d["config4"]["workload"] and "2 rank(s)" in d["config"]["sharding"]
+    assert d["units"].startswith("N=1 only") and d["configs"].startswith("N=1 only")
+    # whole-job value: both ranks' samples over the slower rank's time
+    assert abs(d["value"] - 2 * 24 * 1 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]

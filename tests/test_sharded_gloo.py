@@ -244,8 +244,11 @@ def _worker_hip_modes(rank, world, port, S, out_dir):
     r = gp.predict_sharded_pack(os.path.join(out_dir, "g.pk"), np.array([0.3, 0.6]), mean_ite="root", draws="root",
                                 spp=2, z=z, to_host=True)
     out = {"has": np.array([r.meanITE is not None, r.draws is not None]), "ms": r.meanSATE, "vs": r.varSATE}
+    # the library's own normals (Philox, seed 11): every rank places its block in the ensemble (gpslc_set_ensemble)
+    rs = gp.predict_sharded_pack(os.path.join(out_dir, "g.pk"), np.array([0.3, 0.6]), draws="root", spp=2, seed=11,
+                                 to_host=True)
     if rank == 0:
-        out.update(mi=r.meanITE, dr=r.draws)
+        out.update(mi=r.meanITE, dr=r.draws, dr_seeded=rs.draws)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()
@@ -271,6 +274,9 @@ def test_world_size_2_real_hip_path_root_gather_of_mean_ite_and_draws(tmp_path, 
     assert np.array_equal(d0["mi"], mi) and np.array_equal(d0["dr"], dr)
     for d in (d0, d1):
         assert np.array_equal(d["ms"], ms) and np.array_equal(d["vs"], vs)
+    # seeded draws do not depend on the sharding: two ranks = one process, bit for bit (seed + rank did not)
+    dr_seeded = gp.predict(g, np.array([0.3, 0.6]), spp=2, seed=11, want_draws=True)[3]
+    assert np.array_equal(d0["dr_seeded"], dr_seeded)
 
 
 def test_shard_range_partitions_exactly():
