@@ -96,6 +96,13 @@ struct GemmArgs {
     int fuse;         // 1 (accumulate launches of one tile column, mj == 1): each item also applies the panel
     TRef F;           //    product with tile (0, fk) of F = the inverted diagonal blocks (see k_tilegemm.hip)
     int fk;
+    int chain;        // fuse launches only: tile_fused_chain_kernel — item 0 of every batch element is a CHAIN: tile (i0, j0),
+                      // the augmented-row tile (short_row0, j0) (panel product only), then the update of diagonal tile
+                      // (i0, i0) over [k0, k1] (with the augmented tile (short_row0, i0) riding along), its Cholesky and
+                      // inverse (F tile (0, i0), info / info_base as launch_diag): the next column's launch finds its
+                      // diagonal block ready.  Items t >= 1 are the tiles (i0 + t, j0).
+    int* info;        // chain launches: per-batch-element info words and the code base of tile row 0 (launch_diag's)
+    int info_base;
     int* queue;       // optional: 16 zero-initialised ints (per-XCD ticket counters [0..8), exit counters [8..16))
                       // owned by the launching stream; the kernel leaves them zeroed again.  null = static stride
     const unsigned short* order;  // optional (ii, jj) pairs: output-tile visiting order (L2-blocked), or null

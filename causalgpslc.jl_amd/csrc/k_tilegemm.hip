@@ -29,6 +29,7 @@
 //   * XCD-aware work split: XCD x (blockIdx % 8) owns the x-th contiguous run of work items, so the
 //     workgroups that share an L2 work on neighbouring tiles of the same matrices.
 #include "gpslc_internal.h"
+#include "diag_block.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -387,6 +388,141 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
 // they do not displace the B(k, kk) panel (shared by the ~24 items of a matrix) and inv(L_kk) in L2 (+1.8 % on the
 // kernel, profiles/r03_ab_experiments.md §3).
 // ---------------------------------------------------------------------------------------
+// One work item of the strip kernel: tile (ti, tj) of batch element b.  no_update: the tile needs the panel product
+// only (its column update was done elsewhere, or there is none: first column of a panel).
+template <int WD>
+__device__ __forceinline__ void strip_item(const GemmArgs& g, const int b, const int ti, const int tj, const bool no_update,
+                                           const int nslab, double* lA, double* lB, const int tid, const int lane,
+                                           const int wave, const int li, const int lg, const int frow_a, const int frow_b,
+                                           const int (&loff)[4], const long long item) {
+    double* __restrict__ Ct = tref_tile(g.C, b, ti, tj);
+    // augmented right-hand-side tiles hold `short_rows` live rows: a wave whose strip lies below them only helps
+    // with the staging (its rows keep their zeros: never loaded, never stored)
+    const bool live = !(g.short_rows > 0 && ti >= g.short_row0 && 32 * wave >= g.short_rows);
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (GP_DBG_ON(g)) st0 = __builtin_amdgcn_s_memtime();
+
+    d4 acc[2][8];
+    if (live) {
+        const double* __restrict__ Cl = Ct + (lg * GP_TS + 32 * wave + li);
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m][n][v] = __builtin_nontemporal_load(Cl + (16 * n + 4 * v) * GP_TS + 16 * m);
+    }
+
+    if (nslab > 0 && !no_update) {
+        d2 ra[4], rb[4], ra2[4], rb2[4];
+        auto gload = [&](int s, d2 (&xa)[4], d2 (&xb)[4]) {
+            const int kk = g.k0 + (s >> 3);
+            const int so = (s & 7) * (KS * GP_TS);
+            const double* pa = tref_tile(g.A, b, ti, kk) + so;
+            const double* pb = tref_tile(g.B, b, tj, kk) + so;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xa[u] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2));
+                xb[u] = *reinterpret_cast<const d2*>(pb + (tid + 256 * u) * 2);
+            }
+        };
+        auto lstore = [&](int buf, const d2 (&xa)[4], const d2 (&xb)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                *reinterpret_cast<d2*>(lA + buf * OPER_LDS + loff[u]) = xa[u];
+                *reinterpret_cast<d2*>(lB + buf * OPER_LDS + loff[u]) = xb[u];
+            }
+        };
+        auto compute = [&](int buf) {
+            if (!live) return;
+            const double* pa = lA + buf * OPER_LDS + frow_a;
+            const double* pb = lB + buf * OPER_LDS + frow_b;
+#pragma unroll
+            for (int ks = 0; ks < KS / 4; ++ks) {
+                double af[2], bf[8];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af[m] = pa[ks * 4 * LROW + 16 * m];
+#pragma unroll
+                for (int n = 0; n < 8; ++n) bf[n] = pb[ks * 4 * LROW + 16 * n];
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][n] = mfma_step<1>(bf[n], af[m], acc[m][n]);
+            }
+        };
+        gload(0, ra, rb);
+        lstore(0, ra, rb);
+        gload(1, ra, rb);          // nslab is a multiple of 8
+        __syncthreads();
+        if (GP_DBG_ON(g)) st1 = __builtin_amdgcn_s_memtime();
+        for (int s = 0; s < nslab; s += 2) {
+            if (s + 2 < nslab) gload(s + 2, ra2, rb2);
+            compute(0);
+            lstore(1, ra, rb);
+            __syncthreads();
+            if (s + 3 < nslab) gload(s + 3, ra, rb);
+            compute(1);
+            if (s + 2 < nslab) lstore(0, ra2, rb2);
+            __syncthreads();
+        }
+    }
+    if (GP_DBG_ON(g)) st2 = __builtin_amdgcn_s_memtime();
+
+    if (live) {
+        // fragment (nc, n, v) of W = inv(L_kk): W[16 nc + li][16 n + 4 v + lg], element (c, c') at c' * 128 + c
+        const double* __restrict__ Wl = tref_tile(g.F, b, 0, g.fk) + (lg * GP_TS + li);
+        double* __restrict__ Co = Ct + (lg * GP_TS + 32 * wave + li);
+        // the 144 live fragments in the order of use, WD groups (WD x 128 MFMA clocks) ahead through a register ring
+        double wn[WD];
+        int pc = 0, pn = 0, pv = 0;        // next fragment to request (compile-time after unrolling)
+#pragma unroll
+        for (int q = 0; q < WD; ++q) {
+            wn[q] = Wl[(16 * pn + 4 * pv) * GP_TS + 16 * pc];
+            if (++pv == 4) { pv = 0; if (++pn > pc) { pn = 0; ++pc; } }
+        }
+        int q = 0;
+#pragma unroll
+        for (int nc = 0; nc < 8; ++nc) {
+            d4 st[2];
+            st[0] = (d4){0.0, 0.0, 0.0, 0.0};
+            st[1] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+                if (n <= nc) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const double w = wn[q % WD];
+                        if (pc < 8) {
+                            wn[q % WD] = Wl[(16 * pn + 4 * pv) * GP_TS + 16 * pc];
+                            if (++pv == 4) { pv = 0; if (++pn > pc) { pn = 0; ++pc; } }
+                        }
+                        ++q;
+                        st[0] = mfma_step<0>(w, acc[0][n][v], st[0]);
+                        st[1] = mfma_step<0>(w, acc[1][n][v], st[1]);
+                    }
+                }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                __builtin_nontemporal_store(st[0][v], Co + (16 * nc + 4 * v) * GP_TS);
+                __builtin_nontemporal_store(st[1][v], Co + (16 * nc + 4 * v) * GP_TS + 16);
+            }
+        }
+    }
+    if (GP_DBG_ON(g)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned long long* d = g.dbg + (size_t)item * 8;
+            d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3;
+            d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            d[6] = __builtin_amdgcn_s_memrealtime();
+            d[7] = blockIdx.x;
+        }
+    }
+}
+
 template <int WD>
 __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -431,164 +567,7 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
         if (g.sym >= 2 && ti == tj && !(g.short_rows > 0 && ti >= g.short_row0)) break;   // tile_syrk_diag_kernel's
         // sym == 3: the augmented tile was already updated (it rode with the diagonal item); panel product only
         const bool no_update = g.sym == 3 && g.short_rows > 0 && ti >= g.short_row0 && tj < g.short_row0;
-
-        double* __restrict__ Ct = tref_tile(g.C, b, ti, tj);
-        // augmented right-hand-side tiles hold `short_rows` live rows: a wave whose strip lies below them only helps
-        // with the staging (its rows keep their zeros: never loaded, never stored)
-        const bool live = !(g.short_rows > 0 && ti >= g.short_row0 && 32 * wave >= g.short_rows);
-        unsigned long long st0 = 0, st1 = 0, st2 = 0;
-        if (GP_DBG_ON(g)) st0 = __builtin_amdgcn_s_memtime();
-
-        d4 acc[2][8];
-#ifdef STRIP_NO_CLOAD      // timing-only A/B knob (make variant): accumulators zeroed, results are garbage
-        for (int n = 0; n < 8; ++n) { acc[0][n] = (d4){0.0, 0.0, 0.0, 0.0}; acc[1][n] = (d4){0.0, 0.0, 0.0, 0.0}; }
-        if (false) {
-#else
-        if (live) {
-#endif
-            const double* __restrict__ Cl = Ct + (lg * GP_TS + 32 * wave + li);
-#pragma unroll
-            for (int n = 0; n < 8; ++n)
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        acc[m][n][v] = __builtin_nontemporal_load(Cl + (16 * n + 4 * v) * GP_TS + 16 * m);
-        }
-
-        if (nslab > 0 && !no_update) {
-            d2 ra[4], rb[4], ra2[4], rb2[4];
-            auto gload = [&](int s, d2 (&xa)[4], d2 (&xb)[4]) {
-                const int kk = g.k0 + (s >> 3);
-                const int so = (s & 7) * (KS * GP_TS);
-                const double* pa = tref_tile(g.A, b, ti, kk) + so;
-                const double* pb = tref_tile(g.B, b, tj, kk) + so;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    xa[u] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2));
-                    xb[u] = *reinterpret_cast<const d2*>(pb + (tid + 256 * u) * 2);
-                }
-            };
-            auto lstore = [&](int buf, const d2 (&xa)[4], const d2 (&xb)[4]) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    *reinterpret_cast<d2*>(lA + buf * OPER_LDS + loff[u]) = xa[u];
-                    *reinterpret_cast<d2*>(lB + buf * OPER_LDS + loff[u]) = xb[u];
-                }
-            };
-            auto compute = [&](int buf) {
-                if (!live) return;
-                const double* pa = lA + buf * OPER_LDS + frow_a;
-                const double* pb = lB + buf * OPER_LDS + frow_b;
-#ifdef STRIP_PIPE
-                double afn[2], bfn[8];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) afn[m] = pa[16 * m];
-#pragma unroll
-                for (int n = 0; n < 8; ++n) bfn[n] = pb[16 * n];
-#pragma unroll
-                for (int ks = 0; ks < KS / 4; ++ks) {
-                    double af[2], bf[8];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) af[m] = afn[m];
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) bf[n] = bfn[n];
-                    if (ks + 1 < KS / 4) {
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) afn[m] = pa[(ks + 1) * 4 * LROW + 16 * m];
-#pragma unroll
-                        for (int n = 0; n < 8; ++n) bfn[n] = pb[(ks + 1) * 4 * LROW + 16 * n];
-                    }
-#pragma unroll
-                    for (int n = 0; n < 8; ++n)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) acc[m][n] = mfma_step<1>(bf[n], af[m], acc[m][n]);
-                }
-#else
-#pragma unroll
-                for (int ks = 0; ks < KS / 4; ++ks) {
-                    double af[2], bf[8];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) af[m] = pa[ks * 4 * LROW + 16 * m];
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) bf[n] = pb[ks * 4 * LROW + 16 * n];
-#pragma unroll
-                    for (int n = 0; n < 8; ++n)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) acc[m][n] = mfma_step<1>(bf[n], af[m], acc[m][n]);
-                }
-#endif
-            };
-            gload(0, ra, rb);
-            lstore(0, ra, rb);
-            gload(1, ra, rb);          // nslab is a multiple of 8
-            __syncthreads();
-            if (GP_DBG_ON(g)) st1 = __builtin_amdgcn_s_memtime();
-            for (int s = 0; s < nslab; s += 2) {
-                if (s + 2 < nslab) gload(s + 2, ra2, rb2);
-                compute(0);
-                lstore(1, ra, rb);
-                __syncthreads();
-                if (s + 3 < nslab) gload(s + 3, ra, rb);
-                compute(1);
-                if (s + 2 < nslab) lstore(0, ra2, rb2);
-                __syncthreads();
-            }
-        }
-        if (GP_DBG_ON(g)) st2 = __builtin_amdgcn_s_memtime();
-
-        if (live) {
-            // fragment (nc, n, v) of W = inv(L_kk): W[16 nc + li][16 n + 4 v + lg], element (c, c') at c' * 128 + c
-            const double* __restrict__ Wl = tref_tile(g.F, b, 0, g.fk) + (lg * GP_TS + li);
-            double* __restrict__ Co = Ct + (lg * GP_TS + 32 * wave + li);
-            // the 144 live fragments in the order of use, WD groups (WD x 128 MFMA clocks) ahead through a register ring
-            double wn[WD];
-            int pc = 0, pn = 0, pv = 0;        // next fragment to request (compile-time after unrolling)
-#pragma unroll
-            for (int q = 0; q < WD; ++q) {
-                wn[q] = Wl[(16 * pn + 4 * pv) * GP_TS + 16 * pc];
-                if (++pv == 4) { pv = 0; if (++pn > pc) { pn = 0; ++pc; } }
-            }
-            int q = 0;
-#pragma unroll
-            for (int nc = 0; nc < 8; ++nc) {
-                d4 st[2];
-                st[0] = (d4){0.0, 0.0, 0.0, 0.0};
-                st[1] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int n = 0; n < 8; ++n)
-                    if (n <= nc) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const double w = wn[q % WD];
-                            if (pc < 8) {
-                                wn[q % WD] = Wl[(16 * pn + 4 * pv) * GP_TS + 16 * pc];
-                                if (++pv == 4) { pv = 0; if (++pn > pc) { pn = 0; ++pc; } }
-                            }
-                            ++q;
-                            st[0] = mfma_step<0>(w, acc[0][n][v], st[0]);
-                            st[1] = mfma_step<0>(w, acc[1][n][v], st[1]);
-                        }
-                    }
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    __builtin_nontemporal_store(st[0][v], Co + (16 * nc + 4 * v) * GP_TS);
-                    __builtin_nontemporal_store(st[1][v], Co + (16 * nc + 4 * v) * GP_TS + 16);
-                }
-            }
-        }
-        if (GP_DBG_ON(g)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned long long st3 = __builtin_amdgcn_s_memtime();
-            if (tid == 0) {
-                unsigned long long* d = g.dbg + (size_t)item * 8;
-                d[0] = st0; d[1] = st1; d[2] = st2; d[3] = st3;
-                d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-                d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-                d[6] = __builtin_amdgcn_s_memrealtime();
-                d[7] = blockIdx.x;
-            }
-        }
+        strip_item<WD>(g, b, ti, tj, no_update, nslab, lA, lB, tid, lane, wave, li, lg, frow_a, frow_b, loff, item);
         } while (0);
         if (g.queue) {
             if (tid == 0) s_ticket = ticket;
@@ -607,6 +586,259 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
         }
     }
 }
+
+#ifdef GPSLC_DIAG
+// ---------------------------------------------------------------------------------------
+// Chained in-panel column (round 4) — MEASUREMENT BUILD ONLY (-DGPSLC_DIAG, GPSLC_CHAIN=1|2): built, parity-green, and
+// SLOWER than the three launches it replaces at every size (profiles/r04_ab_experiments.md §3); kept for the A/B record.
+// Left-looking column k used to be three dependent launches: the update of the diagonal
+// tile (tile_syrk_diag_kernel), its Cholesky + inverse (diag_potrf_inv_v2_kernel: one workgroup per matrix, a latency
+// chain of 8 x 16 pivots that leaves the MFMA pipe idle — 9 % of the GPU time at N = 1024) and the strip kernel above.
+// Two of the three are latency bound and nothing can run beside them: the persistent tile kernels own every workgroup
+// slot (two HIP streams + free slots: +1.7 %, profiles/r04_ab_experiments.md).  Here the launch of column k also PREPARES
+// column k + 1: the workgroup that finishes tile (k+1, k) — the last missing operand of the diagonal update of column
+// k + 1 — goes on, inside the same work item, to
+//     (aug, k)            panel product of the augmented right-hand-side tile of column k (short: live rows only)
+//     C(k+1, k+1) -= sum_{kk in [k0, k]} L(k+1, kk) L(k+1, kk)^T        lower triangle, 9 sub-tiles per wave
+//     C(aug, k+1) -= sum_kk L(aug, kk) L(k+1, kk)^T                     the augmented rows ride along (MT row blocks)
+//     L(k+1, k+1), inv(L(k+1, k+1))                                     on the packed image the update leaves in LDS
+// while the other workgroups — its partner on the CU first of all — stream the remaining tiles of column k through the
+// MFMA pipe.  One launch per column; the diagonal tile never makes its HBM round trip between update and factorisation.
+// Every operand of the chain is either final before the launch or written by this very workgroup (release fence +
+// barrier + acquire fence before it is read back through L2).  Arithmetic and summation orders are those of the
+// three kernels it replaces (same device functions / same MFMA chains): the factor is bit-identical.
+// ---------------------------------------------------------------------------------------
+template <int W, int MT, bool TOLDS>
+__device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, const int td, const int kd1, double* smem,
+                                                const int tid, const int lane) {
+    // diagonal tile (td, td) -= sum_{kk in [g.k0, kd1)} A(td, kk) A(td, kk)^T -> packed LDS image (smem); augmented tile
+    // (g.short_row0, td) likewise -> HBM.  Layouts and MFMA order: syrk_diag_wave below.
+    double* lA = smem;
+    double* lG = smem + 2 * OPER_LDS;
+    int loff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = tid + 256 * u;
+        loff[u] = (q >> 6) * LROW + (q & 63) * 2;
+    }
+    const bool glive = MT > 0 && ((tid & 63) * 2) < 16 * MT;
+    const int nslab = (kd1 - g.k0) * (GP_TS / KS);
+    const int li = lane & 15, lg = lane >> 4;
+    const int fbase = lg * LROW + li;
+    double* __restrict__ Cd = tref_tile(g.C, b, td, td) + (lg * GP_TS + li);
+    double* __restrict__ Cg = MT > 0 ? tref_tile(g.C, b, g.short_row0, td) + (lg * GP_TS + li) : nullptr;
+
+    d4 a0c[W + 1], a1c[8 - W];     // sub-tiles (W, cb) and (7 - W, cb)
+#pragma unroll
+    for (int cb = 0; cb <= W; ++cb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a0c[cb][v] = Cd[(16 * cb + 4 * v) * GP_TS + 16 * W];
+#pragma unroll
+    for (int cb = 0; cb < 8 - W; ++cb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a1c[cb][v] = Cd[(16 * cb + 4 * v) * GP_TS + 16 * (7 - W)];
+    d4 ag[MT > 0 ? MT : 1][2];
+    if (MT > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                ag[m][0][v] = Cg[(16 * W + 4 * v) * GP_TS + 16 * m];
+                ag[m][1][v] = Cg[(16 * (7 - W) + 4 * v) * GP_TS + 16 * m];
+            }
+    }
+    d2 ra[4], ra2[4], rg[4];
+    auto gload = [&](int s, d2 (&xa)[4]) {
+        const int kk = g.k0 + (s >> 3);
+        const double* pa = tref_tile(g.A, b, td, kk) + (s & 7) * (KS * GP_TS);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xa[u] = *reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2);
+    };
+    auto gload_g = [&](int s) {
+        if (MT > 0 && glive) {
+            const int kk = g.k0 + (s >> 3);
+            const double* pg = tref_tile(g.A, b, g.short_row0, kk) + (s & 7) * (KS * GP_TS);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rg[u] = *reinterpret_cast<const d2*>(pg + (tid + 256 * u) * 2);
+        }
+    };
+    auto lstore = [&](int buf, const d2 (&xa)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(lA + buf * OPER_LDS + loff[u]) = xa[u];
+    };
+    auto lstore_g = [&](int buf) {
+        if (MT > 0 && glive) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(lG + buf * OPER_LDS + loff[u]) = rg[u];
+        }
+    };
+    auto compute = [&](int buf) {
+        const double* pa = lA + buf * OPER_LDS + fbase;
+        const double* pg = lG + buf * OPER_LDS + fbase;
+#pragma unroll
+        for (int ks = 0; ks < KS / 4; ++ks) {
+            double bf[8 - W];
+#pragma unroll
+            for (int cb = 0; cb < 8 - W; ++cb) bf[cb] = pa[ks * 4 * LROW + 16 * cb];
+            const double r0 = pa[ks * 4 * LROW + 16 * W];
+            const double r1 = pa[ks * 4 * LROW + 16 * (7 - W)];
+#pragma unroll
+            for (int cb = 0; cb <= W; ++cb) a0c[cb] = mfma_step<1>(bf[cb], r0, a0c[cb]);
+#pragma unroll
+            for (int cb = 0; cb < 8 - W; ++cb) a1c[cb] = mfma_step<1>(bf[cb], r1, a1c[cb]);
+            if (MT > 0) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const double gf = pg[ks * 4 * LROW + 16 * m];
+                    ag[m][0] = mfma_step<1>(bf[W], gf, ag[m][0]);
+                    ag[m][1] = mfma_step<1>(bf[7 - W], gf, ag[m][1]);
+                }
+            }
+        }
+    };
+    gload(0, ra);
+    gload_g(0);
+    lstore(0, ra);
+    lstore_g(0);
+    gload(1, ra);
+    __syncthreads();
+    for (int s = 0; s < nslab; s += 2) {
+        if (s + 2 < nslab) gload(s + 2, ra2);
+        gload_g(s + 1);
+        compute(0);
+        lstore(1, ra);
+        lstore_g(1);
+        __syncthreads();
+        if (s + 3 < nslab) gload(s + 3, ra);
+        if (s + 2 < nslab) gload_g(s + 2);
+        compute(1);
+        if (s + 2 < nslab) { lstore(0, ra2); lstore_g(0); }
+        __syncthreads();
+    }
+    if (TOLDS) {
+        // the staging buffers are dead (last barrier): the updated lower blocks become the packed image of the factorisation
+        // — block (i, j) at ((i (i + 1) / 2 + j) << 8), element (r, c) at c * 16 + r; acc[v] = element (li, lg + 4 v)
+#pragma unroll
+        for (int cb = 0; cb <= W; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) smem[(((W * (W + 1)) / 2 + cb) << 8) + (lg + 4 * v) * 16 + li] = a0c[cb][v];
+#pragma unroll
+        for (int cb = 0; cb < 8 - W; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) smem[((((7 - W) * (8 - W)) / 2 + cb) << 8) + (lg + 4 * v) * 16 + li] = a1c[cb][v];
+    } else {     // back to the tile: the diagonal-block kernel factorises it in the next launch
+#pragma unroll
+        for (int cb = 0; cb <= W; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Cd[(16 * cb + 4 * v) * GP_TS + 16 * W] = a0c[cb][v];
+#pragma unroll
+        for (int cb = 0; cb < 8 - W; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Cd[(16 * cb + 4 * v) * GP_TS + 16 * (7 - W)] = a1c[cb][v];
+    }
+    if (MT > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                Cg[(16 * W + 4 * v) * GP_TS + 16 * m] = ag[m][0][v];
+                Cg[(16 * (7 - W) + 4 * v) * GP_TS + 16 * m] = ag[m][1][v];
+            }
+    }
+}
+
+#define CHAIN_LDS_BYTES (DIAG2_LDS_BYTES > GEMM_LDS_BYTES ? DIAG2_LDS_BYTES : GEMM_LDS_BYTES)
+
+template <int WD, int MT, bool POTRF>
+__global__ __launch_bounds__(256, 2) void tile_fused_chain_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    double* lA = smem;                       // [2][KS][LROW]
+    double* lB = smem + 2 * OPER_LDS;        // [2][KS][LROW]
+
+    const long long W = (long long)g.ntiles * g.nbatch;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int gx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+    const long long wq = W >> 3, wrm = W & 7;
+    const long long x0 = xcd * wq + (xcd < wrm ? xcd : wrm);
+    const long long xc = wq + (xcd < wrm ? 1 : 0);
+
+    const int frow_a = lg * LROW + 32 * wave + li;
+    const int frow_b = lg * LROW + li;
+    int loff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int q = tid + 256 * u;
+        loff[u] = (q >> 6) * LROW + (q & 63) * 2;
+    }
+    const int nslab = (g.k1 - g.k0) * (GP_TS / KS);
+
+    __shared__ int s_ticket;
+    long long it = local;
+    while (it < xc) {
+        int ticket = 0;
+        if (g.queue && tid == 0) ticket = atomicAdd(&g.queue[xcd], 1);
+        // batch-major item order: the chains are spread evenly over the launch (all chains first — longest items first —
+        // measured WORSE: the diagonal-tile updates, 9 MFMAs per wave and k-step, then run beside each other instead of
+        // beside MFMA-dense strip items)
+        const long long item = x0 + it;
+        const int b = (int)(item / g.ntiles);
+        const int t = (int)(item - (long long)b * g.ntiles);
+        // t == 0 is the chain: tile (k+1, k), then the augmented tile of column k (panel product only: updated by the
+        // previous chain or by the launch before it); one call site, so the item body is instantiated once
+        const int nsub = (t == 0 && MT > 0) ? 2 : 1;
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int ti = sub == 1 ? g.short_row0 : g.i0 + t;
+            strip_item<WD>(g, b, ti, g.j0, sub == 1 || nslab == 0, nslab, lA, lB, tid, lane, wave, li, lg, frow_a, frow_b,
+                           loff, item);
+        }
+        if (t == 0) {
+            const int td = g.i0;                               // the next column: k + 1
+            // L(k+1, k) and L(aug, k) were stored by this workgroup: make them visible to all of its waves through L2
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            switch (wave) {
+                case 0: syrk_chain_wave<0, MT, POTRF>(g, b, td, g.k1 + 1, smem, tid, lane); break;
+                case 1: syrk_chain_wave<1, MT, POTRF>(g, b, td, g.k1 + 1, smem, tid, lane); break;
+                case 2: syrk_chain_wave<2, MT, POTRF>(g, b, td, g.k1 + 1, smem, tid, lane); break;
+                default: syrk_chain_wave<3, MT, POTRF>(g, b, td, g.k1 + 1, smem, tid, lane); break;
+            }
+            if (POTRF)   // (the first barrier of the factorisation publishes the image)
+                diag_potrf_inv_v2_body(smem, tref_tile(g.C, b, td, td), tref_tile(g.F, b, 0, td), g.info + b,
+                                       g.info_base + GP_TS * td, tid, true);
+        }
+        if (g.queue) {
+            if (tid == 0) s_ticket = ticket;
+            __syncthreads();
+            it = (long long)gx + s_ticket;
+            __syncthreads();
+        } else {
+            it += gx;
+        }
+    }
+    if (g.queue && tid == 0) {
+        __threadfence();
+        if (atomicAdd(&g.queue[8 + xcd], 1) == gx - 1) {
+            g.queue[xcd] = 0;
+            g.queue[8 + xcd] = 0;
+        }
+    }
+}
+
+template <int MT, bool POTRF>
+static void launch_chain_t(const GemmArgs& g, unsigned grid, hipStream_t st) {
+    static DeviceOnce once;
+    const int bytes = POTRF ? CHAIN_LDS_BYTES : GEMM_LDS_BYTES;
+    lds_opt_in(once, (const void*)tile_fused_chain_kernel<FUSE_WD, MT, POTRF>, bytes);
+    hipLaunchKernelGGL((tile_fused_chain_kernel<FUSE_WD, MT, POTRF>), dim3(grid), dim3(256), bytes, st, g);
+}
+
+#endif  // GPSLC_DIAG (chained in-panel column)
 
 // ---------------------------------------------------------------------------------------
 // Diagonal tiles of a symmetric update:  C(t, t) -= sum_kk A(t, kk) A(t, kk)^T, lower triangle only.
@@ -823,6 +1055,19 @@ void launch_tile_gemm(const GemmArgs& g, hipStream_t st) {
     }
     if (g.diag_skip == 2) {
         if (g.accumulate) launch_one<1, 2>(g, grid, st); else launch_one<0, 2>(g, grid, st);
+        return;
+    }
+#endif
+#ifdef GPSLC_DIAG
+    if (g.fuse && g.accumulate && g.chain) {
+        const int mt = g.short_rows > 0 ? (g.short_rows + 15) / 16 : 0;     // callers chain only for mt <= 2
+        if (g.chain >= 2) {      // GPSLC_CHAIN=2: the diagonal block factorised inside the chain too
+            if (mt == 0) launch_chain_t<0, true>(g, grid, st);
+            else if (mt == 1) launch_chain_t<1, true>(g, grid, st);
+            else launch_chain_t<2, true>(g, grid, st);
+        } else if (mt == 0) launch_chain_t<0, false>(g, grid, st);
+        else if (mt == 1) launch_chain_t<1, false>(g, grid, st);
+        else launch_chain_t<2, false>(g, grid, st);
         return;
     }
 #endif

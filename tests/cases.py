@@ -76,3 +76,17 @@ GOLDEN_GRID = [(n, shape, bt) for n in (1, 3, 24, 150) for shape in SHAPES for b
 
 def golden_name(n, shape, bt):
     return f"n{n}_{shape}_{'bin' if bt else 'real'}"
+
+
+def draw_bounds(lam_min, lam_max, znorm, refnorm=0.0):
+    """Bounds on ||draw_gpu - (M + chol(C) z)|| for C = CovITE + jitter with the given extreme eigenvalues.
+
+    `bound`: SURVEY §8d's 1e-8 ||L_c|| ||z|| where the conditioning permits it, i.e. max(1e-8, 1e-15 cond(C)) — a Cholesky
+    factor moves by cond(C) x the 1e-15 relative rounding of forming C.  `tight` (None when cond >= 1e8): what fp64 actually
+    delivers on a reasonably conditioned matrix, 1e-9 ||L_c|| ||z|| — observed errors sit four orders of magnitude below
+    even that (7e-12 at N = 4096, cond 1.3e7), so a regression of the CovITE factor by a factor 1e4 no longer passes."""
+    cond = lam_max / max(lam_min, 1e-300)
+    lc = float(np.sqrt(lam_max))
+    bound = max(1e-8, 1e-15 * cond) * lc * znorm + 1e-9 * refnorm
+    tight = (1e-9 * lc * znorm + 1e-12 * refnorm) if cond < 1e8 else None
+    return bound, tight, cond

@@ -178,6 +178,9 @@ def test_ite_draws_with_supplied_normals(gp, n, shape, bt, pred_noise):
             # conditioning permits it, the conditioning-limited one otherwise.
             bound = max(1e-8, 1e-15 * kappa)
             assert np.linalg.norm(dev_out - dev_ref) <= bound * lc_norm * np.linalg.norm(z[:, col])
+            # and the tight guard wherever cond < 1e8 (the 1e-3 jitter cases): 1e-9 ||L_c|| ||z||
+            _, tight, _ = cases.draw_bounds(ev[0], ev[-1], np.linalg.norm(z[:, col]), np.linalg.norm(ref[:, col]))
+            assert tight is None or np.linalg.norm(dev_out - dev_ref) <= tight, (s, d, kappa)
 
 
 @pytest.mark.parametrize("spp,L", [(1, 1), (10, 1), (17, 3), (40, 2), (100, 1), (130, 3)])

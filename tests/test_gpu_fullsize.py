@@ -14,6 +14,7 @@ import os
 import numpy as np
 import pytest
 
+import cases
 import gpslc_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -119,10 +120,14 @@ def test_unit_b_with_draws_n1024_default_jitter(gp):
     M, Cv = orc.ite_distributions(smp, X, T, Y, doT)
     ref = orc.ite_samples(M, Cv, spp, z)
     for s in range(S):
-        lc_norm = np.sqrt(np.linalg.eigvalsh(Cv[s])[-1])          # ||L_c||_2 = sqrt(lambda_max(CovITE + jitter))
+        ev = np.linalg.eigvalsh(Cv[s])
+        lc_norm = np.sqrt(ev[-1])                                  # ||L_c||_2 = sqrt(lambda_max(CovITE + jitter))
         for d in range(spp):
             col = s * spp + d
-            assert np.linalg.norm(out[:, col] - ref[:, col]) <= 1e-8 * lc_norm * np.linalg.norm(z[:, col])
+            err = np.linalg.norm(out[:, col] - ref[:, col])
+            assert err <= 1e-8 * lc_norm * np.linalg.norm(z[:, col])
+            _, tight, cond = cases.draw_bounds(ev[0], ev[-1], np.linalg.norm(z[:, col]), np.linalg.norm(ref[:, col]))
+            assert tight is None or err <= tight, (err, tight, cond)
 
 
 def test_unit_b_draw_n4096_default_jitter_against_the_literal_restatement(gp):
@@ -140,8 +145,10 @@ def test_unit_b_draw_n4096_default_jitter_against_the_literal_restatement(gp):
     ev = np.linalg.eigvalsh(Cv[0])
     Lc = np.linalg.cholesky(Cv[0])
     ref = M[0] + Lc @ z[:, 0, 0, 0]
-    bound = max(1e-8, 1e-15 * ev[-1] / ev[0]) * np.sqrt(ev[-1]) * np.linalg.norm(z) + 1e-9 * np.linalg.norm(ref)
-    assert np.linalg.norm(dr[0][:, 0] - ref) <= bound
+    bound, tight, cond = cases.draw_bounds(ev[0], ev[-1], np.linalg.norm(z), np.linalg.norm(ref))
+    err = np.linalg.norm(dr[0][:, 0] - ref)
+    assert err <= bound
+    assert tight is None or err <= tight, (err, tight, cond)        # cond ~ 1e7 here: the tight guard applies
     assert np.max(np.abs(mi[:, 0, 0] - M[0])) <= 1e-6 * np.max(np.abs(M[0])) + 1e-12
 
 
@@ -167,8 +174,10 @@ def test_unit_b_pairs_and_robust_factor_n2048(gp):
             ev = np.linalg.eigvalsh(cov)
             Lc = np.linalg.cholesky(cov)
             ref = m + Lc @ z[:, 0, s, l]
-            bound = max(1e-8, 1e-15 * ev[-1] / ev[0]) * np.sqrt(ev[-1]) * np.linalg.norm(z[:, 0, s, l])
-            assert np.linalg.norm(dr[l][:, s * spp] - ref) <= bound + 1e-9 * np.linalg.norm(ref), (s, l)
+            bound, tight, cond = cases.draw_bounds(ev[0], ev[-1], np.linalg.norm(z[:, 0, s, l]), np.linalg.norm(ref))
+            err = np.linalg.norm(dr[l][:, s * spp] - ref)
+            assert err <= bound, (s, l)
+            assert tight is None or err <= tight, (s, l, err, tight, cond)
             assert np.max(np.abs(mi[:, s, l] - m)) <= 1e-8 * np.max(np.abs(m)) + 1e-12
 
 
@@ -232,6 +241,31 @@ def test_config5_mixed_precision_n16384_against_the_fp64_oracle(gp):
     # the MeanITE vector itself against the oracle (not only through its mean): fp64 structured restatement, doT = 1
     m_ref = _structured_mean_ite(p, X, T, Y, 1.0)
     assert np.max(np.abs(mi[:, 1, 1] - m_ref)) <= 1e-6 * np.max(np.abs(m_ref)) + 1e-12
+    _check_config5_literal_golden(gp, X, T, Y, objid)
+
+
+def _check_config5_literal_golden(gp, X, T, Y, objid):
+    """The same configuration against the LITERAL restatement at full size (5 kernel builds, 3 symmetric-indefinite
+    solves, 4 GEMMs at N = 16384: 11 minutes on this container's 8 cores and ~30 GB of host memory, so the suite cannot run
+    it) through its committed outputs: tests/golden/config5_literal.npz, written by tests/golden/make_golden_config5.py from
+    oracle.ite_distributions + conditional_sate for (S = 1, sample 0, doT = 1).  Both precision modes; the inputs are
+    regenerated here from the same seeds and their checksums compared with the ones stored beside the outputs."""
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5_literal.npz"))
+    n, D, K, S = (int(v) for v in gold["shape"])
+    assert (n, D, K, S) == (16384, 16, 4, 1) and float(gold["doT"]) == 1.0
+    post = gp.synth.make_posterior(n, D, K, S, objid)
+    chk = np.array([X.sum(), T.sum(), Y.sum(), post["U"].sum(), post["uyLS"].sum(), post["xyLS"].sum(),
+                    post["tyLS"][0], post["yNoise"][0], post["yScale"][0]])
+    assert np.allclose(chk, gold["in_checksums"], rtol=1e-13, atol=0), "the synthetic generator moved: regenerate the golden"
+    rm, rv, m_ref = float(gold["meanSATE"]), float(gold["varSATE"]), gold["meanITE"]
+    for fp32, tol in ((False, 1e-9), (True, 1e-6)):
+        g = gp.GPSLCObject(X, T, Y, post["U"], post["uyLS"], post["xyLS"], post["tyLS"], post["yNoise"], post["yScale"],
+                           fp32_kernel=fp32)
+        ms, vs, mi = gp.predict(g, [1.0], want_mean_ite=True)
+        assert abs(ms[0, 0] - rm) <= tol * abs(rm) + 1e-12, (fp32, ms[0, 0], rm)
+        assert abs(vs[0, 0] - rv) <= tol * abs(rv) + 1e-9 * float(post["yScale"][0]) * (1.0 if fp32 else 1e-3), (fp32, vs[0, 0], rv)
+        assert np.max(np.abs(mi[:, 0, 0] - m_ref)) <= tol * np.max(np.abs(m_ref)) + 1e-12, fp32
+        # north_star's 1e-6 in both modes; fp64 is asserted at 1e-9 (observed 1e-13 .. 1e-14, profiles/r03_config5_literal.md)
 
 
 def _structured_mean_ite(p, X, T, Y, doT):

@@ -62,3 +62,30 @@ def test_philox_known_answer():
 def test_philox_normals_moments():
     z = orc.philox_normals(1234, 7, 200000)
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+
+
+@pytest.mark.gpu      # no GPU call in it: it rides with the GPU-box run because that host has the cores (about 15 s there)
+@pytest.mark.skipif((os.cpu_count() or 1) < 32, reason="one 16384 x 16384 Cholesky + 2 GB matrices: 6 minutes on 8 cores")
+def test_config5_literal_golden_agrees_with_the_structured_restatement_at_full_size():
+    """tests/golden/config5_literal.npz holds the LITERAL restatement's outputs at BASELINE configs[4]'s size (N = 16384,
+    D 16, nU 4, binary treatment; 11 minutes and ~30 GB to regenerate, tests/golden/make_golden_config5.py).  Here, on the
+    CPU: its inputs are what the generator yields today, and the STRUCTURED restatement — the algebra the HIP path uses —
+    reproduces its MeanSATE / VarSATE at the same size (one Cholesky of a 16384 x 16384 matrix: about a minute)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "synth", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "causalgpslc.jl_amd", "synth.py"))
+    synth = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(synth)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5_literal.npz"))
+    n, D, K, S = (int(v) for v in gold["shape"])
+    X, T, Y, objid = synth.make_dataset(n, D, binary_t=True)
+    post = synth.make_posterior(n, D, K, S, objid)
+    chk = np.array([X.sum(), T.sum(), Y.sum(), post["U"].sum(), post["uyLS"].sum(), post["xyLS"].sum(),
+                    post["tyLS"][0], post["yNoise"][0], post["yScale"][0]])
+    assert np.allclose(chk, gold["in_checksums"], rtol=1e-13, atol=0)
+    assert abs(float(gold["meanITE"].mean()) - float(gold["meanSATE"])) <= 1e-12 * abs(float(gold["meanSATE"])) + 1e-16
+    p = orc.PosteriorSample(post["uyLS"][:, 0], post["xyLS"][:, 0], float(post["tyLS"][0]), float(post["yNoise"][0]),
+                            float(post["yScale"][0]), post["U"][:, :, 0])
+    ms, vs, _, _ = orc.structured_sate(p, X, T, Y, np.array([float(gold["doT"])]))
+    assert abs(ms[0] - float(gold["meanSATE"])) <= 1e-9 * abs(float(gold["meanSATE"]))
+    assert abs(vs[0] - float(gold["varSATE"])) <= 1e-9 * abs(float(gold["varSATE"]))
