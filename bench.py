@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--timing-only", action="store_true",
                     help="measurement only (timing-only kernel variants whose results are garbage by construction): ignore "
                          "the status of the calls and skip every result check; the line is labelled")
-    return ap.parse_args()
+    return ap.parse_args([x for x in sys.argv[1:] if x != "--"])
 
 
 def git_blob_sha(path):
@@ -144,8 +144,11 @@ def self_launch(a):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    # "--" before this script's own flags: torch.distributed.run's parser otherwise claims every flag that is a prefix of
+    # one of its own (--n 1024 -> "ambiguous option: --nnodes, --nproc-per-node, ...", --nu 2 -> --numa-binding)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), "--"] + \
+          [x for x in sys.argv[1:] if x != "--"]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)

@@ -318,6 +318,7 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st, int prof_base = 0) {
         // sym == 3: the off-diagonal augmented-row tiles are not this kernel's either (they ride with the diagonal items)
         double short_exec = short_items;
         if (g.sym == 3 && short_items > 0) short_exec = (g.shape == 0) ? 1.0 : 0.0;
+        if (g.skip_gdiag && g.shape == 0 && short_exec >= 1.0) short_exec -= 1.0;     // the augmented diagonal tile is not run
         const double rows = GP_TS * ((double)g.ntiles - short_items - diag_out * diag_items)
                           + (double)g.short_rows * short_exec;
         double flop = 2.0 * GP_TS * GP_TS * rows * (double)(g.k1 - g.k0) * (double)g.nbatch;
@@ -401,7 +402,7 @@ TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstri
 // panel, one right-looking trailing update (K = pw*128) per panel.
 void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, long long inv_bstride,
                  int* info, int info_base, int nb, hipStream_t st, int aug_rows = 0, int prof_base = 0,
-                 bool robust = false, int info_div = 1) {
+                 bool robust = false, int info_div = 1, bool skip_aug_diag = false) {
     // aug_rows > 0: the tile rows nt.. hold only that many live rows in total (right-hand sides);
     // a single augmented tile row is the common case and the only one the kernel shortens
     const int short_rows = (aug_rows > 0 && ntot == nt + 1) ? aug_rows : 0;
@@ -485,10 +486,14 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             g.short_row0 = nt; g.short_rows = short_rows;
             gemm(c, g, st, prof_base);
         }
-        if (k == kend - 1 && ntot - kend > 0) {   // trailing update with the whole panel
+        // skip_aug_diag (single short augmented row, epilogue sums from the rows of R): the augmented diagonal tile is
+        // never updated — after the last panel it would be the launch's only item
+        const bool skip_gd = skip_aug_diag && short_rows > 0;
+        if (k == kend - 1 && ntot - kend > (skip_gd ? 1 : 0)) {   // trailing update with the whole panel
             GemmArgs g{};
             g.A = M; g.B = M; g.C = M;
             const int m = ntot - kend;
+            g.skip_gdiag = skip_gd ? 1 : 0;
             g.shape = 0; g.i0 = kend; g.j0 = kend; g.mi = m; g.mj = m; g.sym = aug_sym(sym_mode(), short_rows);
             g.k0 = ka; g.k1 = kend; g.accumulate = 1; g.nbatch = nb; g.ntiles = m * (m + 1) / 2;
             g.order = tri_order(c, m);
@@ -652,14 +657,21 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         ra.T = c->dT; ra.Y = io.Y; ra.y_sstride = io.y_sstride; ra.tyLS = io.p.tyLS; ra.doT = io.doT; ra.s0 = s0;
         ra.n = n; ra.nt = nt; ra.naug = naug; ra.L = with_sums ? L : 0; ra.with_sums = with_sums ? 1 : 0;
         ra.part = part; ra.bsum = bsum; ra.ksum = ksum; ra.sumdelta = sumdelta; ra.M = M;
+        static const int epi_rows_on = diag_env("GPSLC_EPI_ROWS", 1);      // measurement switch (A/B of the extra tile update)
+        const bool epi_rows = (naug == 1) && epi_rows_on;
+        {
+            const int live = (with_sums ? L : 0) + 1;                         // right-hand sides: Y and one c_l per level
+            ra.live_rows = (epi_rows && live <= 32) ? 16 * ((live + 15) / 16) : 0;
+        }
         launch_rhs(ra, nb, st);
 
-        potrf_tiles(c, M, nt, ntot, inv, inv_bs, io.info + s0, 0, nb, st, (with_sums ? L : 0) + 1);
+        potrf_tiles(c, M, nt, ntot, inv, inv_bs, io.info + s0, 0, nb, st, (with_sums ? L : 0) + 1, 0, false, 1, epi_rows);
 
         EpiArgs ea{};
         ea.M = M; ea.n = n; ea.nt = nt; ea.naug = naug; ea.L = with_sums ? L : 0; ea.s0 = s0; ea.S = io.S;
         ea.sumdelta = sumdelta; ea.pred_noise = io.pred_noise;
         ea.meanSATE = io.meanSATE; ea.varSATE = io.varSATE; ea.logdet = io.logdet; ea.quad = io.quad;
+        ea.from_rows = epi_rows ? 1 : 0;
         launch_epilogue(ea, nb, st);
 
         if (want_mean) {

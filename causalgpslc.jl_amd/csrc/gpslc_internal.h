@@ -96,6 +96,8 @@ struct GemmArgs {
     int fuse;         // 1 (accumulate launches of one tile column, mj == 1): each item also applies the panel
     TRef F;           //    product with tile (0, fk) of F = the inverted diagonal blocks (see k_tilegemm.hip)
     int fk;
+    int skip_gdiag;   // the (short) augmented diagonal tile (short_row0, short_row0) is not an item of this launch: nobody
+                      // reads -R R^T (EpiArgs::from_rows)
     int chain;        // fuse launches only: tile_fused_chain_kernel — item 0 of every batch element is a CHAIN: tile (i0, j0),
                       // the augmented-row tile (short_row0, j0) (panel product only), then the update of diagonal tile
                       // (i0, i0) over [k0, k1] (with the augmented tile (short_row0, i0) riding along), its Cholesky and
@@ -153,6 +155,9 @@ struct RhsArgs {
     long long s0; int n, nt, naug, L; int with_sums;
     const double* part; double* bsum; double* ksum; double* sumdelta;  // bsum/ksum [b][Np], sumdelta [b][L]
     TRef M;
+    int live_rows;   // > 0 (single augmented tile row of <= 32 right-hand sides, epilogue sums from the rows of R): only the
+                     // first live_rows (a multiple of 16, <= 32) rows of the augmented tiles are written and the augmented
+                     // diagonal tile not at all — every reader of those tiles touches the live 16- / 32-row blocks only
 };
 void launch_rhs(const RhsArgs& r, int nbatch, hipStream_t st);
 
@@ -161,6 +166,8 @@ struct EpiArgs {
     const double* sumdelta; double pred_noise;
     double* meanSATE; double* varSATE;   // S x L or null
     double* logdet; double* quad;        // S or null
+    int from_rows;   // 1 (single augmented tile row): z.z, z.w_l, w_l.w_l are summed from the rows of R themselves — the
+                     // augmented diagonal tile is then never updated (potrf_tiles(..., skip_aug_diag))
 };
 void launch_epilogue(const EpiArgs& e, int nbatch, hipStream_t st);
 

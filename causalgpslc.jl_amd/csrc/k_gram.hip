@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void rhs_tiles_kernel(RhsArgs a) {
     const long long s = a.s0 + b;
     double* tile = tref_tile(a.M, b, a.nt + au, j);
     if (j >= a.nt) {
+        if (a.live_rows > 0) return;      // the augmented diagonal tile has no reader (EpiArgs::from_rows, skip_aug_diag)
         for (int idx = tid; idx < GP_TSQ; idx += 256) tile[idx] = 0.0;
         return;
     }
@@ -316,6 +317,26 @@ __global__ __launch_bounds__(256) void rhs_tiles_kernel(RhsArgs a) {
     const double tl = a.tyLS[s];
     const double wt = 1.0 / (tl * tl);
     // element (row q, col c) at c*128 + q; thread -> consecutive q for coalescing
+    if (a.live_rows > 0) {
+        // 32 live rows at most: 32 x 128 elements, 256 contiguous bytes per column (the other 96 rows of the tile keep
+        // whatever the workspace held: no kernel reads them, and a row of an MFMA product depends on its own row only)
+        for (int idx = tid; idx < 32 * GP_TS; idx += 256) {
+            const int c = idx >> 5, q = idx & 31;
+            if (q >= a.live_rows) continue;
+            const int gj = j * GP_TS + c;
+            double v = 0.0;
+            if (gj < a.n) {
+                if (q == 0) v = a.Y[s * a.y_sstride + gj];
+                else if (q <= a.L) {
+                    const double dt = a.T[gj] - a.doT[q - 1];
+                    const double r = gp_exp_neg(-((dt * dt) * wt));
+                    v = r * bs[gj] - ks[gj];
+                }
+            }
+            tile[c * GP_TS + q] = v;
+        }
+        return;
+    }
     for (int idx = tid; idx < GP_TSQ; idx += 256) {
         const int c = idx >> 7, q = idx & 127;
         const int gq = au * GP_TS + q;        // right-hand side index
@@ -355,13 +376,45 @@ __global__ __launch_bounds__(256) void epilogue_kernel(EpiArgs e) {
         acc += log(dt[c * GP_TS + c]);
     }
     const double ld = 2.0 * block_sum_256(acc, red);
+    const double nn = (double)e.n;
+    if (e.from_rows) {
+        // The Schur block -R R^T used to come from one more tile update (an item streaming two full operand panels for
+        // (L + 1)^2 live entries: 1.9 % of the GPU time at N = 1024) of which only z.z, z.w_l and w_l.w_l are read.  Here
+        // they are summed from R directly: right-hand side q of column i sits at tile (nt, i / 128)[(i % 128) * 128 + q].
+        // Wave w takes q = w, w + 4, ... (q = 0: z itself), lanes stride the columns; fixed butterfly: deterministic.
+        // w_l == 0 (doT == T everywhere) gives exact zeros, as before.
+        const int lane = tid & 63, wave = tid >> 6;
+        const int ncol = e.nt * GP_TS;
+        const int nq = (e.meanSATE || e.varSATE) ? e.L : 0;
+        if (tid == 0 && e.logdet) e.logdet[s] = ld;
+        for (int q = wave; q <= nq; q += 4) {
+            double zw = 0.0, ww = 0.0;
+            for (int i = lane; i < ncol; i += 64) {
+                const double* col = tref_tile(e.M, b, e.nt, i >> 7) + (long long)(i & 127) * GP_TS;
+                const double z = col[0], w = col[q];
+                zw = fma(z, w, zw);
+                ww = fma(w, w, ww);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { zw += __shfl_xor(zw, o, 64); ww += __shfl_xor(ww, o, 64); }
+            if (lane == 0) {
+                if (q == 0) { if (e.quad) e.quad[s] = ww; }
+                else {
+                    const int l = q - 1;
+                    const double sd = e.sumdelta[(long long)b * e.L + l];
+                    if (e.meanSATE) e.meanSATE[s + e.S * l] = zw / nn;
+                    if (e.varSATE) e.varSATE[s + e.S * l] = ((sd - ww) + nn * e.pred_noise) / (nn * nn);
+                }
+            }
+        }
+        return;
+    }
     const double* g00 = tref_tile(e.M, b, e.nt, e.nt);
     if (tid == 0) {
         if (e.logdet) e.logdet[s] = ld;
         if (e.quad) e.quad[s] = -g00[0];
     }
     if (e.meanSATE == nullptr && e.varSATE == nullptr) return;
-    const double nn = (double)e.n;
     for (int l = tid; l < e.L; l += 256) {
         const int q = 1 + l, au = q >> 7, qq = q & 127;
         const double wz = -tref_tile(e.M, b, e.nt + au, e.nt)[0 * GP_TS + qq];

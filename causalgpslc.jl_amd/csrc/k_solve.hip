@@ -589,38 +589,110 @@ __global__ __launch_bounds__(256) void draws_mfma_kernel(DrawArgs a) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) acc[m][q] = (d4s){0.0, 0.0, 0.0, 0.0};
-        for (int jt = 0; jt <= ib; ++jt) {
-            const double* __restrict__ t = tref_tile(a.Lc, b, ib, jt) + r0;
-#pragma unroll 1
-            for (int kc = 0; kc < GP_TS / DR_KC; ++kc) {
-                // this lane's rows of the 16 column groups of the chunk: 16 independent 16-byte loads in flight
-                d2s lv[DR_KC / 4];
-#pragma unroll
+#ifdef DRAWS_NO_PIPE      // A/B knob (variant build): the un-pipelined chunk loop for every NQ
+        if constexpr (false) {
+#else
+        if constexpr (NQ == 1) {
+#endif
+            // Chunks of 64 columns of the tile row, software-pipelined (round 4): the 16 loads of chunk c + 1 are in flight
+            // while chunk c runs its staging barriers and MFMAs.  Two things make that real: the z loads of a chunk are issued
+            // BEFORE the factor loads of the next one (vmcnt counts in order: waiting for a younger load would wait for the
+            // prefetch as well), and the two barriers order LDS traffic only (__syncthreads() waits vmcnt(0): every load in
+            // flight).  Same chunk order and MFMA chains as before: bit-identical draws.
+            constexpr int ZPT = DR_KC * ND / 256;               // z values a thread stages per chunk
+            const int nchunk = (ib + 1) * (GP_TS / DR_KC);
+            auto load_l = [&](int c, d2s (&lv)[DR_KC / 4]) {
+                const double* __restrict__ t = tref_tile(a.Lc, b, ib, c / (GP_TS / DR_KC)) + r0;
+                const int kc = c % (GP_TS / DR_KC);
+    #pragma unroll
                 for (int kk = 0; kk < DR_KC / 4; ++kk)
                     lv[kk] = *reinterpret_cast<const d2s*>(t + (kc * DR_KC + 4 * kk + lq) * GP_TS);
-                __syncthreads();
-                for (int idx = tid; idx < DR_KC * ND; idx += 256) {
+            };
+            auto load_z = [&](int c, double (&zr)[ZPT]) {
+                const int jt = c / (GP_TS / DR_KC), kc = c % (GP_TS / DR_KC);
+    #pragma unroll
+                for (int u = 0; u < ZPT; ++u) {
+                    const int idx = tid + 256 * u;
                     const int k = idx & (DR_KC - 1), dd = idx / DR_KC;
                     const long long g = (long long)jt * GP_TS + kc * DR_KC + k;
-                    zs[k * ZLD + dd] = (dd < nd && g < n) ? zu[g + n * (d0 + dd)] : 0.0;
+                    zr[u] = (dd < nd && g < n) ? zu[g + n * (d0 + dd)] : 0.0;
                 }
-                __syncthreads();
+            };
+            auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+            auto run_chunk = [&](int c, d2s (&lv)[DR_KC / 4], const double (&zr)[ZPT]) {
+                const int jt = c / (GP_TS / DR_KC), kc = c % (GP_TS / DR_KC);
+                lds_barrier();                                   // the previous chunk's readers are done with zs
+    #pragma unroll
+                for (int u = 0; u < ZPT; ++u) {
+                    const int idx = tid + 256 * u;
+                    zs[(idx & (DR_KC - 1)) * ZLD + idx / DR_KC] = zr[u];
+                }
+                lds_barrier();
                 if (jt == ib) {     // diagonal tile: only the lower triangle belongs to L_c
-#pragma unroll
+    #pragma unroll
                     for (int kk = 0; kk < DR_KC / 4; ++kk) {
-                        const int c = kc * DR_KC + 4 * kk + lq;
-                        if (c > r0) lv[kk].x = 0.0;
-                        if (c > r0 + 1) lv[kk].y = 0.0;
+                        const int cc = kc * DR_KC + 4 * kk + lq;
+                        if (cc > r0) lv[kk].x = 0.0;
+                        if (cc > r0 + 1) lv[kk].y = 0.0;
                     }
                 }
-#pragma unroll
+    #pragma unroll
                 for (int kk = 0; kk < DR_KC / 4; ++kk) {
-                    const double* zr = zs + (4 * kk + lq) * ZLD + li;
-#pragma unroll
+                    const double* zrow = zs + (4 * kk + lq) * ZLD + li;
+    #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        const double zf = zr[16 * q];
+                        const double zf = zrow[16 * q];
                         acc[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, lv[kk].x, acc[0][q], 0, 0, 0);
                         acc[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, lv[kk].y, acc[1][q], 0, 0, 0);
+                    }
+                }
+            };
+            d2s lvA[DR_KC / 4], lvB[DR_KC / 4];
+            double zA[ZPT], zB[ZPT];
+            load_z(0, zA);
+            load_l(0, lvA);
+            for (int c = 0; c < nchunk; c += 2) {        // nchunk is even (two chunks per tile)
+                load_z(c + 1, zB);
+                load_l(c + 1, lvB);
+                run_chunk(c, lvA, zA);
+                if (c + 2 < nchunk) { load_z(c + 2, zA); load_l(c + 2, lvA); }
+                run_chunk(c + 1, lvB, zB);
+            }
+            lds_barrier();                                   // before the next pass of draws (d0) restages zs
+        } else {     // spp > 16: two staging sets of 16 loads no longer fit the register file at two waves per SIMD, and beyond 32 draws the pass is MFMA-bound anyway
+            for (int jt = 0; jt <= ib; ++jt) {
+                const double* __restrict__ t = tref_tile(a.Lc, b, ib, jt) + r0;
+    #pragma unroll 1
+                for (int kc = 0; kc < GP_TS / DR_KC; ++kc) {
+                    // this lane's rows of the 16 column groups of the chunk: 16 independent 16-byte loads in flight
+                    d2s lv[DR_KC / 4];
+    #pragma unroll
+                    for (int kk = 0; kk < DR_KC / 4; ++kk)
+                        lv[kk] = *reinterpret_cast<const d2s*>(t + (kc * DR_KC + 4 * kk + lq) * GP_TS);
+                    __syncthreads();
+                    for (int idx = tid; idx < DR_KC * ND; idx += 256) {
+                        const int k = idx & (DR_KC - 1), dd = idx / DR_KC;
+                        const long long g = (long long)jt * GP_TS + kc * DR_KC + k;
+                        zs[k * ZLD + dd] = (dd < nd && g < n) ? zu[g + n * (d0 + dd)] : 0.0;
+                    }
+                    __syncthreads();
+                    if (jt == ib) {     // diagonal tile: only the lower triangle belongs to L_c
+    #pragma unroll
+                        for (int kk = 0; kk < DR_KC / 4; ++kk) {
+                            const int c = kc * DR_KC + 4 * kk + lq;
+                            if (c > r0) lv[kk].x = 0.0;
+                            if (c > r0 + 1) lv[kk].y = 0.0;
+                        }
+                    }
+    #pragma unroll
+                    for (int kk = 0; kk < DR_KC / 4; ++kk) {
+                        const double* zr = zs + (4 * kk + lq) * ZLD + li;
+    #pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const double zf = zr[16 * q];
+                            acc[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, lv[kk].x, acc[0][q], 0, 0, 0);
+                            acc[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, lv[kk].y, acc[1][q], 0, 0, 0);
+                        }
                     }
                 }
             }

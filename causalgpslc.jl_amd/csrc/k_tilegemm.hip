@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
         if (g.sym >= 2 && ti == tj && !(g.short_rows > 0 && ti >= g.short_row0)) break;
         // sym == 3: the augmented-row tiles of the columns that have a full-size diagonal tile ride with it
         if (g.sym == 3 && g.short_rows > 0 && ti >= g.short_row0 && tj < g.short_row0) break;
+        if (g.skip_gdiag && ti == tj && g.short_rows > 0 && ti >= g.short_row0) break;   // -R R^T is not needed (EpiArgs::from_rows)
         if (GP_DIAG_SKIP(g) == 3 && g.short_rows > 0 && ti >= g.short_row0) break;   // timing-only: price of the short tiles
 
         double* __restrict__ Ct = tref_tile(g.C, b, ti, tj);
@@ -417,8 +418,13 @@ __device__ __forceinline__ void strip_item(const GemmArgs& g, const int b, const
     if (nslab > 0 && !no_update) {
         d2 ra[4], rb[4], ra2[4], rb2[4];
         auto gload = [&](int s, d2 (&xa)[4], d2 (&xb)[4]) {
+            #ifdef STRIP_SLAB0   // timing-only A/B knob (make variant): every operand slab is slab 0 of the panel (L2 hits): prices the operand HBM traffic
+            const int kk = g.k0;
+            const int so = 0;
+#else
             const int kk = g.k0 + (s >> 3);
             const int so = (s & 7) * (KS * GP_TS);
+#endif
             const double* pa = tref_tile(g.A, b, ti, kk) + so;
             const double* pb = tref_tile(g.B, b, tj, kk) + so;
 #pragma unroll

@@ -93,7 +93,7 @@ def test_two_rank_rehearsal_line_carries_the_whole_contract():
     env["GPSLC_BENCH_REHEARSAL"] = "1"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--", "--gpus", "2", "--steps", "1",
            "--warmup", "1", "--n", "640", "--d", "4", "--nu", "1", "--samples-per-step", "24", "--config4-levels", "8",
            "--config4-steps", "1", "--cpu-units", "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
