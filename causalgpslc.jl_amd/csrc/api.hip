@@ -127,6 +127,7 @@ struct gpslc_ctx {
     // two pinned bounce chunks for large device -> pageable-host hand-overs (copy_out_large), allocated on first use
     char* bounce[2] = {nullptr, nullptr};
     std::vector<double> hX, hT, hY;
+    std::vector<double> stage_f, stage_rest;   // host staging of gpslc_nodes_logpdf's batched pass (grown, never shrunk)
     std::string err;
     std::vector<int32_t> last_info;
     // cached factor of the last dense covariance given to gpslc_mvn_logpdf (SigmaU is constant per data set)
@@ -665,6 +666,9 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         }
         launch_rhs(ra, nb, st);
 
+        // NB: the MeanITE pass takes K alpha as Y - yNoise alpha (k_solve.hip, ite_mean_kernel): it relies on alpha solving
+        // EXACTLY (K_gram + yNoise I) alpha = Y.  Any future jitter, robust fallback or different right-hand side in this
+        // factorisation must be reflected there (tests: test_mean_ite_tiny_noise_and_near_coincident_levels).
         potrf_tiles(c, M, nt, ntot, inv, inv_bs, io.info + s0, 0, nb, st, (with_sums ? L : 0) + 1, 0, false, 1, epi_rows);
 
         EpiArgs ea{};
@@ -684,7 +688,6 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
             ia.n = n; ia.nX = io.nX; ia.nU = io.nU; ia.nt = nt; ia.L = L; ia.doT = io.doT; ia.alpha = alpha;
             ia.Y = io.Y; ia.y_sstride = io.y_sstride; ia.yNoise = io.p.yNoise;
             ia.f32 = (c->flags & GPSLC_FLAG_FP32_KERNEL) ? 1 : 0;
-            ia.binary_t = c->binary_t ? 1 : 0;
             if (meanITE) {
                 ia.meanITE = meanITE; ia.si = 1; ia.ss = n; ia.sl = (long long)n * io.S;
                 launch_ite_mean(ia, nb, st);
@@ -1496,20 +1499,36 @@ int gpslc_nodes_logpdf(gpslc_ctx* c, int32_t count, const gpslc_node* nodes, dou
         // feature blocks and per-set targets).  Nodes with fewer than nF_max feature columns are padded with zero
         // columns of lengthscale 1: a padding column adds (0 * 1 - 0 * 1)^2 = +0.0 to every squared distance, so a
         // node's Gram matrix — and its score — is bit-identical to the one its own feature count would give.
+        // Staging lives in the ctx (this call sits in the MCMC inner loop: no allocation once the buffers have grown),
+        // and nodes that all share ONE feature block — the nX `:X => k => :X` nodes, F = U for every k — hand it over once
+        // (f_shared) instead of count padded copies.
         const size_t n = (size_t)c->n;
-        std::vector<double> Fp(n * (size_t)nF_max * count, 0.0), lsp((size_t)std::max(nF_max, 1) * count, 1.0);
-        std::vector<double> sc((size_t)count), no((size_t)count), tg(n * (size_t)count);
+        bool same_f = true;
+        for (int i = 1; i < count; ++i) same_f = same_f && nodes[i].F == nodes[0].F && nodes[i].nF == nodes[0].nF;
+        std::vector<double>& Fp = c->stage_f;
+        std::vector<double>& rest = c->stage_rest;       // [ls | scale | noise | targets]
+        const size_t ls_n = (size_t)std::max(nF_max, 1) * count;
+        rest.resize(ls_n + 2 * (size_t)count + n * (size_t)count);
+        double* lsp = rest.data();
+        double* sc = lsp + ls_n;
+        double* no = sc + count;
+        double* tg = no + count;
+        std::fill(lsp, lsp + ls_n, 1.0);
+        if (!same_f) {
+            Fp.resize(n * (size_t)nF_max * count);
+            std::fill(Fp.begin(), Fp.end(), 0.0);
+        }
         for (int i = 0; i < count; ++i) {
             const gpslc_node& q = nodes[i];
             if (q.nF > 0) {
-                memcpy(Fp.data() + (size_t)i * n * nF_max, q.F, n * (size_t)q.nF * sizeof(double));
-                memcpy(lsp.data() + (size_t)i * nF_max, q.ls, (size_t)q.nF * sizeof(double));
+                if (!same_f) memcpy(Fp.data() + (size_t)i * n * nF_max, q.F, n * (size_t)q.nF * sizeof(double));
+                memcpy(lsp + (size_t)i * nF_max, q.ls, (size_t)q.nF * sizeof(double));
             }
             sc[i] = q.scale; no[i] = q.noise;
-            memcpy(tg.data() + (size_t)i * n, q.target, n * sizeof(double));
+            memcpy(tg + (size_t)i * n, q.target, n * sizeof(double));
         }
-        return gp_logpdf_general(c, count, nF_max, nF_max ? Fp.data() : nullptr, 0, nF_max ? lsp.data() : nullptr,
-                                 sc.data(), no.data(), tg.data(), 0, logpdf);
+        const double* Fsrc = nF_max == 0 ? nullptr : (same_f ? nodes[0].F : Fp.data());
+        return gp_logpdf_general(c, count, nF_max, Fsrc, same_f ? 1 : 0, nF_max ? lsp : nullptr, sc, no, tg, 0, logpdf);
     });
 }
 

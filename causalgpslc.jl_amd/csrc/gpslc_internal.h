@@ -187,7 +187,6 @@ struct IteMeanArgs {
     double* meanITE;       // element (i, s, l) at i*si + s*ss + l*sl
     long long si, ss, sl;
     int f32;
-    int binary_t;
 };
 void launch_ite_mean(const IteMeanArgs& a, int nbatch, hipStream_t st);
 

@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void draws_mfma_kernel(DrawArgs a) {
             auto load_l = [&](int c, d2s (&lv)[DR_KC / 4]) {
                 const double* __restrict__ t = tref_tile(a.Lc, b, ib, c / (GP_TS / DR_KC)) + r0;
                 const int kc = c % (GP_TS / DR_KC);
-    #pragma unroll
+#pragma unroll
                 for (int kk = 0; kk < DR_KC / 4; ++kk)
                     lv[kk] = *reinterpret_cast<const d2s*>(t + (kc * DR_KC + 4 * kk + lq) * GP_TS);
             };

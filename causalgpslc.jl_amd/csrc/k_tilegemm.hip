@@ -418,13 +418,8 @@ __device__ __forceinline__ void strip_item(const GemmArgs& g, const int b, const
     if (nslab > 0 && !no_update) {
         d2 ra[4], rb[4], ra2[4], rb2[4];
         auto gload = [&](int s, d2 (&xa)[4], d2 (&xb)[4]) {
-            #ifdef STRIP_SLAB0   // timing-only A/B knob (make variant): every operand slab is slab 0 of the panel (L2 hits): prices the operand HBM traffic
-            const int kk = g.k0;
-            const int so = 0;
-#else
             const int kk = g.k0 + (s >> 3);
             const int so = (s & 7) * (KS * GP_TS);
-#endif
             const double* pa = tref_tile(g.A, b, ti, kk) + so;
             const double* pb = tref_tile(g.B, b, tj, kk) + so;
 #pragma unroll

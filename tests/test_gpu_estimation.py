@@ -438,3 +438,28 @@ def test_multi_level_mfma_mean_ite_path(gp):
                        rng.uniform(0.5, 2, (2, 2)), rng.uniform(0.5, 2, (3, 2)), [0.8, 1.1], [0.6, 0.9], [1.1, 0.7])
     ms, vs, mi = gp.predict(g, [0.75] * 6, want_mean_ite=True)
     assert np.all(mi == 0.0) and np.all(ms == 0.0)
+
+
+@pytest.mark.parametrize("n,shape", [(150, "UX"), (300, "X")])
+def test_mean_ite_tiny_noise_and_near_coincident_levels(gp, n, shape):
+    """MeanITE takes K alpha from the solve itself, K alpha = Y - yNoise alpha (A alpha = Y), instead of a second pass over
+    the pairs.  Where that could bite: a tiny yNoise — K + yNoise I badly conditioned, alpha large, Y - yNoise
+    alpha a cancellation — and intervention levels a hair away from many treatments, where (Ks' - K) alpha itself nearly
+    cancels.  Per element against the literal restatement; the bound scales with cond(A) (any solver's alpha does)."""
+    c = cases.make_case(n, shape, False, S=2, seed=900 + n)
+    c["yNoise"] = np.array([1e-6, 1e-4])
+    T = c["T"]
+    c["doTs"] = np.array([T[3] + 1e-7, T[n // 2] - 1e-7, float(np.median(T)) + 1e-7])
+    obj = cases.gpslc_object(gp, c)
+    ms, vs, mi = gp.predict(obj, c["doTs"], want_mean_ite=True)
+    smp = cases.samples_of(c)
+    for s_ in range(2):
+        for l, doT in enumerate(c["doTs"]):
+            M, Cv = orc.ite_distributions([smp[s_]], c["X"], c["T"], c["Y"], float(doT))
+            ref = M[0]
+            Bm, E = orc._base_and_e(smp[s_], c["X"], c["T"])
+            ev = np.linalg.eigvalsh(Bm * E + smp[s_].yNoise * np.eye(n))
+            cond = ev[-1] / ev[0]
+            tol = max(1e-9, 1e-15 * cond) * np.max(np.abs(ref)) + 1e-12
+            assert np.max(np.abs(mi[:, s_, l] - ref)) <= tol, (s_, l, cond, np.max(np.abs(mi[:, s_, l] - ref)), tol)
+            assert abs(ms[s_, l] - ref.mean()) <= max(1e-9, 1e-15 * cond) * np.max(np.abs(ref)) + 1e-12

@@ -158,6 +158,8 @@ def test_fused_model_score_beyond_the_single_workgroup_kernels_is_one_batched_pa
     assert not ctx.last_info(len(nodes)).any()
     for i, q in enumerate(nodes):          # padding columns add exact zeros: same bits as the node's own pass
         assert gp.nodesLogpdf([q], ctx)[0] == out[i], i
+    # nodes that all share ONE feature block (the :X => k => :X nodes, F = U) hand it over once (f_shared): same bits
+    assert np.array_equal(gp.nodesLogpdf(nodes[:2], ctx), out[:2])
     # a failing node reports its pivot and leaves the others' scores alone
     bad = list(nodes)
     bad[1] = (U, uxLS[1], xScale[1], -5.0, X[:, 1])
