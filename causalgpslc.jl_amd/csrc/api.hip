@@ -731,24 +731,41 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                     // factorisation), column 0 has no update and takes the panel product alone
                     TRef invref = TRef{inv + (long long)g0 * inv_bs, inv_bs, 1, 0, 0, 0};
                     invref.bdiv = lc;
+                    // Left-looking over the whole width (every column update in the strip kernel).  GPSLC_W_PANEL = w > 0
+                    // (measurement build) blocks it like the factorisation instead — left-looking inside panels of w tile
+                    // columns, one right-looking update of everything to the right of a panel on the quadrant kernel.
+                    // Measured in round 4 (profiles/r04_ab_experiments.md §7): w = 4 / 8 / 16 -> 354 / 360 / 363.5 units/s
+                    // against 363 unblocked: with a deep K loop the strip kernel is as fast as the quadrant kernel's
+                    // rectangle update plus the extra pass over W.  Not the default.
+                    static const int wpw_env = diag_env("GPSLC_W_PANEL", 0);
+                    const int wpw = wpw_env <= 0 ? nt : wpw_env;
                     for (int k = 0; k < nt; ++k) {
+                        const int ka = (k / wpw) * wpw;
+                        const int kend = std::min(ka + wpw, nt);
                         GemmArgs g{};
                         g.A = W; g.C = W;
                         g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = nt; g.mj = 1; g.nbatch = ub; g.ntiles = nt;
                         // fused up to a K depth of w_fuse_maxk tiles (measurement switch; +0.7 % fused at every depth)
                         static const int w_fuse_maxk = diag_env("GPSLC_FUSE_W_MAXK", 32);
-                        if (k > 0 && k <= w_fuse_maxk && fuse_mode()) {
-                            g.B = Ls; g.k0 = 0; g.k1 = k; g.accumulate = 1;
+                        if (k > ka && k - ka <= w_fuse_maxk && fuse_mode()) {
+                            g.B = Ls; g.k0 = ka; g.k1 = k; g.accumulate = 1;
                             g.fuse = 1; g.F = invref; g.fk = k;
                             gemm(c, g, st, 3);
-                            continue;
-                        }
-                        if (k > 0) {
-                            g.B = Ls; g.k0 = 0; g.k1 = k; g.accumulate = 1;
+                        } else {
+                            if (k > ka) {
+                                g.B = Ls; g.k0 = ka; g.k1 = k; g.accumulate = 1;
+                                gemm(c, g, st, 3);
+                            }
+                            g.B = invref; g.k0 = k; g.k1 = k + 1; g.accumulate = 0;
                             gemm(c, g, st, 3);
                         }
-                        g.B = invref; g.k0 = k; g.k1 = k + 1; g.accumulate = 0;
-                        gemm(c, g, st, 3);
+                        if (k == kend - 1 && kend < nt) {      // the panel is solved: update everything to its right
+                            GemmArgs t{};
+                            t.A = W; t.B = Ls; t.C = W;
+                            t.shape = 1; t.i0 = 0; t.j0 = kend; t.mi = nt; t.mj = nt - kend;
+                            t.k0 = ka; t.k1 = kend; t.accumulate = 1; t.nbatch = ub; t.ntiles = t.mi * t.mj;
+                            gemm(c, t, st, 3);
+                        }
                     }
                     {   // CovITE (+ jitter) = Delta - W W^T, lower tiles
                         GemmArgs g{};

@@ -184,3 +184,35 @@ def test_nodes_draw_edges(gp):
     with pytest.raises(gp.PosDefException):
         gp.nodesDraw([(F, ls, 1.2, -2.0, z)], ctx)
     assert ctx.last_info(1)[0] > 0
+
+
+def test_set_ensemble_argument_checks_and_default(gp):
+    """gpslc_set_ensemble(ctx, sample_offset, S_total): negative offsets / totals and an offset beyond the ensemble are
+    argument errors (-2 / -3); (0, 0) restores the default; the placement changes the library's own normals only."""
+    ctx = gp.Context(8, 0, 0)
+    lib = ctx.lib
+    assert lib.gpslc_set_ensemble(ctx.h, -1, 10) == -2
+    assert lib.gpslc_set_ensemble(ctx.h, 0, -1) == -3
+    assert lib.gpslc_set_ensemble(ctx.h, 10, 10) == -3
+    assert lib.gpslc_set_ensemble(ctx.h, 3, 10) == 0
+    assert lib.gpslc_set_ensemble(ctx.h, 0, 0) == 0
+    assert lib.gpslc_set_ensemble(None, 0, 0) == -1
+    ctx.close()
+
+
+def test_ensemble_placement_reproduces_the_single_call_streams(gp):
+    """Samples [2, 5) of a 6-sample ensemble predicted on their own with set_ensemble(2, 6) draw exactly the normals the
+    6-sample call draws for them (stream id = (offset + s) + S_total * l), for every level."""
+    import cases
+    c = cases.make_case(40, "UX", False, S=6, seed=77)
+    g = cases.gpslc_object(gp, c)
+    doTs, spp = np.array([0.1, 0.9]), 3
+    full = gp.predict(g, doTs, spp=spp, seed=5, want_draws=True)[3]               # (L, n, S * spp)
+    from causalgpslc_jl_amd.sharded import slice_object
+    part = slice_object(g, 2, 5)
+    part.ctx().set_ensemble(2, 6)
+    got = gp.predict(part, doTs, spp=spp, seed=5, want_draws=True)[3]
+    assert np.array_equal(got, full[:, :, 2 * spp:5 * spp])
+    part.ctx().set_ensemble(0, 0)
+    again = gp.predict(part, doTs, spp=spp, seed=5, want_draws=True)[3]
+    assert not np.array_equal(again, got)                                        # default numbering: other streams
