@@ -48,6 +48,7 @@ HBM_PEAK_GBPS = 8000.0
 # pure fp64 VALU issue time per posterior sample at N=4096 D=8 nU=2, 2.4 GHz: SQ_ACTIVE_INST_VALU x 4 clocks / 1024 SIMDs per
 # 1,024-sample launch (profiles/r03_pmc_gram.md, r03_pmc_ite_mean.md; round 2: 18.6 and 31.4 — table-driven exp, and the
 # MeanITE pass lost one of its two exp per pair)
+C2_HBM_BYTES_PER_SAMPLE = 39.6e6      # profiles/r04_pmc_n1024_per_kernel.md (re-measured when the schedule changes)
 GRAM_VALU_US_N4096 = 17.4
 ITE_MEAN_VALU_US_N4096 = 19.1
 KERNEL_SRC = os.path.join(ROOT, "causalgpslc.jl_amd", "csrc", "k_tilegemm.hip")
@@ -379,6 +380,15 @@ def run_config(gp, synth, np, torch, dev, local_rank, n, D, K, S, L, binary_t, f
            "ms_per_step": 1e3 * dt / steps, "dtype": "f64 factorisation, f32 kernel build" if fp32 else "f64",
            "algorithmic_flop_per_unit": flop, "ceiling_units_per_s": FP64_PEAK_TFLOPS * 1e12 / flop,
            "frac_of_ceiling": val * flop / (FP64_PEAK_TFLOPS * 1e12)}
+    if (n, D, K, L) == (1024, 4, 1, 1) and not fp32:
+        # Config 2 is bandwidth-bound, not MFMA-bound (profiles/r04_ab_experiments.md §5, r04_pmc_n1024_per_kernel.md): the
+        # left-looking schedule moves ~41 MB of HBM traffic per posterior sample (PMC: FETCH_SIZE x 2 + WRITE_SIZE summed over
+        # the kernels of a 4,096-sample chunk), nine times the 4.7 MB matrix.  Round-4 measurement of the round-4 kernels.
+        rec["hbm"] = {"bytes_per_unit": C2_HBM_BYTES_PER_SAMPLE, "achieved": val * C2_HBM_BYTES_PER_SAMPLE / 1e9,
+                      "peak": HBM_PEAK_GBPS, "roofline_unit": "GB/s", "frac": val * C2_HBM_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBPS,
+                      "ceiling_units_per_s": HBM_PEAK_GBPS * 1e9 / C2_HBM_BYTES_PER_SAMPLE,
+                      "note": "the binding roof of this configuration: HBM bytes per sample from the PMC passes of "
+                              "profiles/r04_pmc_n1024_per_kernel.md x samples/s; frac_of_ceiling above is against the MFMA peak"}
     names = ("trailing_update_kernel", "fused_in_panel_kernel")
     for nm, (ln, ms, fl) in zip(names, prof):
         if ln > 0 and ms > 0:

@@ -456,8 +456,18 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             if (g.sym >= 2 && fuse_mode() && ntot - k - 1 > 0) {
                 // diagonal tile first, then its factor + inverse, then ONE pass over the column: update and panel
                 // product of every tile below the diagonal (the column makes one HBM round trip instead of two)
-                if (diag_ready < 1) launch_sym_diag_tiles(g, st);
-                if (diag_ready < 2) launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
+                // GPSLC_DIAG_FOLD (measurement switch, default on): update + factorisation of the diagonal tile in ONE
+                // launch (diag_update_potrf_kernel) instead of tile_syrk_diag_kernel followed by diag_potrf_inv_v2_kernel
+                static const int fold = diag_env("GPSLC_DIAG_FOLD", 1);
+                const bool fold_ok = fold && diag_ready == 0 && info_div == 1;
+                if (fold_ok) {
+                    GemmArgs d = g;
+                    d.F = invref; d.info = info; d.info_base = info_base;
+                    launch_diag_update_potrf(d, g.sym == 3 && short_rows > 0, st);
+                } else {
+                    if (diag_ready < 1) launch_sym_diag_tiles(g, st);
+                    if (diag_ready < 2) launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
+                }
                 diag_ready = 0;
                 g.fuse = 1; g.F = invref; g.fk = k;
                 // Chained launch: the work item of tile (k+1, k) also prepares column k + 1 of the same panel — update of

@@ -142,6 +142,7 @@ struct GramArgs {
 // launchers (implemented in the k_*.hip files); all asynchronous on `st`
 void launch_tile_gemm(const GemmArgs& g, hipStream_t st);
 void launch_syrk_diag(const GemmArgs& g, int carry_aug, hipStream_t st);   // g.mi full-size diagonal tiles from (i0, i0)
+void launch_diag_update_potrf(const GemmArgs& g, int carry_aug, hipStream_t st);  // in-panel diagonal tile: update + factor + inverse
 void launch_diag(const TRef& M, int k, double* inv, long long inv_bstride, int* info,
                  int info_base, int nbatch, hipStream_t st);
 void launch_gram(const GramArgs& g, int nbatch, hipStream_t st);

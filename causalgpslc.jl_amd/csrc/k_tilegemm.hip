@@ -588,7 +588,6 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
     }
 }
 
-#ifdef GPSLC_DIAG
 // ---------------------------------------------------------------------------------------
 // Chained in-panel column (round 4) — MEASUREMENT BUILD ONLY (-DGPSLC_DIAG, GPSLC_CHAIN=1|2): built, parity-green, and
 // SLOWER than the three launches it replaces at every size (profiles/r04_ab_experiments.md §3); kept for the A/B record.
@@ -748,6 +747,48 @@ __device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Diagonal tile of an in-panel column in ONE launch (round 4): update of tile (k, k) over [k0, k1) with the
+// augmented rows riding along (what tile_syrk_diag_kernel<MT> does for it), then — on the packed image the update leaves in
+// LDS, without the HBM round trip of the tile — its Cholesky + inverse (what diag_potrf_inv_v2_kernel does).  One workgroup
+// per matrix, two per CU.  Unlike the chained STRIP launch below this pairs the factorisation's fp64 pivot chains with the
+// diagonal update's sparse MFMA stream (9 MFMAs per wave and k-step between staging waits), not with a dense one.
+// ---------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256, 2) void diag_update_potrf_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.x;
+    const int td = g.i0;
+    switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
+        case 0: syrk_chain_wave<0, MT, true>(g, b, td, g.k1, smem, tid, lane); break;
+        case 1: syrk_chain_wave<1, MT, true>(g, b, td, g.k1, smem, tid, lane); break;
+        case 2: syrk_chain_wave<2, MT, true>(g, b, td, g.k1, smem, tid, lane); break;
+        default: syrk_chain_wave<3, MT, true>(g, b, td, g.k1, smem, tid, lane); break;
+    }
+    diag_potrf_inv_v2_body(smem, tref_tile(g.C, b, td, td), tref_tile(g.F, b, 0, td), g.info + b, g.info_base + GP_TS * td,
+                           tid, true);
+}
+
+template <int MT>
+static void launch_diag_update_potrf_t(const GemmArgs& g, hipStream_t st) {
+    static DeviceOnce once;
+    constexpr int bytes = DIAG2_LDS_BYTES > GEMM_LDS_BYTES ? DIAG2_LDS_BYTES : GEMM_LDS_BYTES;
+    lds_opt_in(once, (const void*)diag_update_potrf_kernel<MT>, bytes);
+    hipLaunchKernelGGL(diag_update_potrf_kernel<MT>, dim3(g.nbatch), dim3(256), bytes, st, g);
+}
+
+// g: A = B = C = the tile matrix, i0 = the column k, [k0, k1) = the panel columns left of it (k1 - k0 >= 1), F / info /
+// info_base as for launch_diag, short_row0 / short_rows = the augmented row when carry_aug
+void launch_diag_update_potrf(const GemmArgs& g, int carry_aug, hipStream_t st) {
+    if (g.nbatch <= 0) return;
+    const int mt = carry_aug ? (g.short_rows + 15) / 16 : 0;
+    if (mt == 0) launch_diag_update_potrf_t<0>(g, st);
+    else if (mt == 1) launch_diag_update_potrf_t<1>(g, st);
+    else launch_diag_update_potrf_t<2>(g, st);
+}
+
+#ifdef GPSLC_DIAG
 #define CHAIN_LDS_BYTES (DIAG2_LDS_BYTES > GEMM_LDS_BYTES ? DIAG2_LDS_BYTES : GEMM_LDS_BYTES)
 
 template <int WD, int MT, bool POTRF>
