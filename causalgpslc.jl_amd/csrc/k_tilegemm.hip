@@ -43,6 +43,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define GP_DIAG_SKIP(g) 0
 #endif
 
+// The trailing-update kernel raises its waves' issue priority around the 64 MFMAs of a slab (s_setprio 1) and drops it for
+// the staging stores, the barrier and the next loads: the wave that HAS MFMAs ready wins the issue slot over its partner's
+// staging instructions.  Measured (profiles/r04_ab_experiments.md §11, three alternating pairs): trailing update 66.4 ->
+// 67.2 TFLOP/s, unit A +0.55 %; priority 3 the same; on the strip kernel -0.3 % (its second phase wants the partner's
+// staging to proceed) -> applied to tile_gemm_nt_kernel only.
+#define MFMA_PRIO_UP __builtin_amdgcn_s_setprio(1)
+#define MFMA_PRIO_DOWN __builtin_amdgcn_s_setprio(0)
+
 #define KS 16
 #define LROW 144                      // padded k-row (doubles)
 #define OPER_LDS (KS * LROW)          // doubles per operand per stage
@@ -279,11 +287,15 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
             if (DIAG == 0) {
                 for (int s = 0; s < nslab; s += 2) {
                     if (s + 2 < nslab) gload(s + 2, ra2, rb2);
+                    MFMA_PRIO_UP;
                     if (ACC) compute(0, s); else compute_p(0, s);
+                    MFMA_PRIO_DOWN;
                     lstore(1, ra, rb);
                     __syncthreads();
                     if (s + 3 < nslab) gload(s + 3, ra, rb);
+                    MFMA_PRIO_UP;
                     if (ACC) compute(1, s + 1); else compute_p(1, s + 1);
+                    MFMA_PRIO_DOWN;
                     if (s + 2 < nslab) lstore(0, ra2, rb2);
                     __syncthreads();
                 }
