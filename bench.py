@@ -52,7 +52,7 @@ C2_HBM_BYTES_PER_SAMPLE = 39.6e6      # profiles/r04_pmc_n1024_per_kernel.md (re
 GRAM_VALU_US_N4096 = 17.4
 ITE_MEAN_VALU_US_N4096 = 19.1
 KERNEL_SRC = os.path.join(ROOT, "causalgpslc.jl_amd", "csrc", "k_tilegemm.hip")
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_tile_gemm.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_tile_gemm.json")
 
 
 def parse():
