@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBPS = 8000.0
 # pure fp64 VALU issue time per posterior sample at N=4096 D=8 nU=2, 2.4 GHz: SQ_ACTIVE_INST_VALU x 4 clocks / 1024 SIMDs per
-# 1,024-sample launch (profiles/r03_pmc_gram.md, r03_pmc_ite_mean.md; round 2: 18.6 and 31.4 — table-driven exp, and the
+# 1,024-sample launch (profiles/r04_pmc_gram.md, r04_pmc_ite_mean.md — unchanged since round 3; round 2: 18.6 and 31.4 — table-driven exp, and the
 # MeanITE pass lost one of its two exp per pair)
 C2_HBM_BYTES_PER_SAMPLE = 39.6e6      # profiles/r04_pmc_n1024_per_kernel.md (re-measured when the schedule changes)
 GRAM_VALU_US_N4096 = 17.4
@@ -662,7 +662,7 @@ def main():
         if launches > 0 and kms > 0:
             ach = kflop / (kms * 1e-3) / 1e12
             # HBM bytes per launch of this kernel from the committed PMC passes of this same command (separate
-            # rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950 correction; tools/profile_r03.sh).  The
+            # rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950 correction; tools/profile_r04.sh).  The
             # summary records the git blob hash of the kernel source it was taken from: a different source today
             # means the number no longer describes this kernel, and it is withheld.
             traffic, tnote = pmc_traffic((n, D, K, L, Sr) == (4096, 8, 2, 1, 1024) and a.max_batch == 0 and a.panel == 0)
@@ -725,8 +725,8 @@ def main():
                 ua["ceiling_shared_datapath_units_per_s"] = 1.0 / (flop_a / (FP64_PEAK_TFLOPS * 1e12) + valu_s)
                 ua["ceiling_shared_datapath_note"] = (
                     f"1 / (flop / peak + {GRAM_VALU_US_N4096} us Gram + {ITE_MEAN_VALU_US_N4096} us MeanITE of pure fp64 VALU "
-                    "issue time per sample at 2.4 GHz, SQ_ACTIVE_INST_VALU of profiles/r03_pmc_gram.md and "
-                    "r03_pmc_ite_mean.md): the MFMA-only ceiling ignores that both instruction classes use the same fp64 units")
+                    "issue time per sample at 2.4 GHz, SQ_ACTIVE_INST_VALU of profiles/r04_pmc_gram.md and "
+                    "r04_pmc_ite_mean.md): the MFMA-only ceiling ignores that both instruction classes use the same fp64 units")
             out["units"]["A"] = ua
         if world > 1:
             out["units"] = "N=1 only (units B / C and the unit-A ceilings are single-GPU measurements: run without --gpus)"
