@@ -56,7 +56,7 @@ def test_launcher_counts_gpus_without_touching_them():
 
 
 def test_committed_bench_line_carries_the_contract_keys():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "sate_rel_err", "units"):
         assert k in d, k
@@ -71,6 +71,14 @@ def test_committed_bench_line_carries_the_contract_keys():
     assert d["config4"]["levels"] == 64 and d["config4"]["parity"]["ok"]
     assert {"c2", "c5"} <= set(d["configs"]) and all(c["parity"]["ok"] for c in d["configs"].values())
     assert d["units"]["A"]["ceiling_shared_datapath_units_per_s"] < d["units"]["A"]["ceiling_units_per_s"]
+    # round 4: config 2 as BASELINE states it (one call, S = 1000) within 10 % of the 8,192-per-step figure; config 2's
+    # binding roof (HBM) stated beside the MFMA fraction; the tight draw guard applied where the conditioning permits it
+    c2, c2l = d["configs"]["c2"], d["configs"]["c2_literal"]
+    assert c2l["samples_per_step"] == 1000 and c2l["parity"]["ok"] and abs(c2l["value"] / c2["value"] - 1.0) <= 0.10
+    assert 0 < c2["hbm"]["frac"] <= 1 and c2["hbm"]["bytes_per_unit"] > 8 * 1024 ** 2 / 2
+    pb = d["units"]["B"]["parity"]
+    assert pb["cond"] < 1e8 and pb["draw_tight_bound"] is not None and pb["draw_err"] <= pb["draw_tight_bound"]
+    assert d["roofline"]["traffic"] is not None and d["roofline"]["traffic"] > 0
 
 
 def _free_port():
