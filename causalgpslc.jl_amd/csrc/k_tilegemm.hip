@@ -55,6 +55,9 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define LROW 144                      // padded k-row (doubles)
 #define OPER_LDS (KS * LROW)          // doubles per operand per stage
 #define GEMM_LDS_BYTES (2 * 2 * OPER_LDS * 8)
+#ifndef SYRK_PF
+#define SYRK_PF 2                      // staging depth (register sets = slabs in flight) of the diagonal-tile update loops
+#endif
 #define FUSE_WD 8                      // inv(L) fragments in flight ahead of their MFMAs (strip kernel)
 
 __device__ __forceinline__ void tri_decode(int t, int& ii, int& jj) {
@@ -633,7 +636,7 @@ __device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, 
         const int q = tid + 256 * u;
         loff[u] = (q >> 6) * LROW + (q & 63) * 2;
     }
-    const bool glive = MT > 0 && ((tid & 63) * 2) < 16 * MT;
+    const bool glive = MT > 0 && tid < 128 * MT;     // one row pair of the augmented slab per thread
     const int nslab = (kd1 - g.k0) * (GP_TS / KS);
     const int li = lane & 15, lg = lane >> 4;
     const int fbase = lg * LROW + li;
@@ -659,31 +662,31 @@ __device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, 
                 ag[m][1][v] = Cg[(16 * (7 - W) + 4 * v) * GP_TS + 16 * m];
             }
     }
-    d2 ra[4], ra2[4], rg[4];
-    auto gload = [&](int s, d2 (&xa)[4]) {
+    // Staging: SYRK_PF register sets, loads SYRK_PF slabs ahead of the MFMAs.  A slab of this update is 9 MFMAs per wave and
+    // k-step — 576 pipe clocks — so its loads need more than one slab time to arrive; the barriers order LDS traffic only
+    // (__syncthreads() waits vmcnt(0): with it the "two slabs ahead" of round 3 was in fact less than one).  The augmented
+    // rows' loads travel with their slab (vmcnt counts in order), one row pair per thread.  Measured (profiles/
+    // r04_ab_experiments.md §12): 2 sets + LDS-only barriers +1.1..2.0 % at N = 1024, 4 sets no better, 8 sets spill.
+    // augmented slab: 16 k-columns x 16 MT live rows = 128 MT row pairs, ONE per thread (tid < 128 MT)
+    d2 rs[SYRK_PF][4], rgs[MT > 0 ? SYRK_PF : 1];
+    const int gcol = tid / (8 * (MT > 0 ? MT : 1)), grp = tid % (8 * (MT > 0 ? MT : 1));
+    auto gload = [&](int s, int set) {
         const int kk = g.k0 + (s >> 3);
         const double* pa = tref_tile(g.A, b, td, kk) + (s & 7) * (KS * GP_TS);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xa[u] = *reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2);
-    };
-    auto gload_g = [&](int s) {
+        for (int u = 0; u < 4; ++u) rs[set][u] = *reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2);
         if (MT > 0 && glive) {
-            const int kk = g.k0 + (s >> 3);
             const double* pg = tref_tile(g.A, b, g.short_row0, kk) + (s & 7) * (KS * GP_TS);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rg[u] = *reinterpret_cast<const d2*>(pg + (tid + 256 * u) * 2);
+            rgs[MT > 0 ? set : 0] = *reinterpret_cast<const d2*>(pg + gcol * GP_TS + 2 * grp);
         }
     };
-    auto lstore = [&](int buf, const d2 (&xa)[4]) {
+    auto lstore = [&](int buf, int set) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(lA + buf * OPER_LDS + loff[u]) = xa[u];
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(lA + buf * OPER_LDS + loff[u]) = rs[set][u];
+        if (MT > 0 && glive)
+            *reinterpret_cast<d2*>(lG + buf * OPER_LDS + gcol * LROW + 2 * grp) = rgs[MT > 0 ? set : 0];
     };
-    auto lstore_g = [&](int buf) {
-        if (MT > 0 && glive) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(lG + buf * OPER_LDS + loff[u]) = rg[u];
-        }
-    };
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto compute = [&](int buf) {
         const double* pa = lA + buf * OPER_LDS + fbase;
         const double* pg = lG + buf * OPER_LDS + fbase;
@@ -708,24 +711,18 @@ __device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, 
             }
         }
     };
-    gload(0, ra);
-    gload_g(0);
-    lstore(0, ra);
-    lstore_g(0);
-    gload(1, ra);
-    __syncthreads();
-    for (int s = 0; s < nslab; s += 2) {
-        if (s + 2 < nslab) gload(s + 2, ra2);
-        gload_g(s + 1);
-        compute(0);
-        lstore(1, ra);
-        lstore_g(1);
-        __syncthreads();
-        if (s + 3 < nslab) gload(s + 3, ra);
-        if (s + 2 < nslab) gload_g(s + 2);
-        compute(1);
-        if (s + 2 < nslab) { lstore(0, ra2); lstore_g(0); }
-        __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SYRK_PF; ++u) gload(u, u);          // nslab is a multiple of 8 >= SYRK_PF
+    lstore(0, 0);
+    lds_barrier();
+    for (int s = 0; s < nslab; s += SYRK_PF) {
+#pragma unroll
+        for (int u = 0; u < SYRK_PF; ++u) {                  // slab s + u sits in LDS buffer u & 1
+            if (s + u + SYRK_PF < nslab) gload(s + u + SYRK_PF, u);      // set u went to LDS one step ago
+            compute(u & 1);
+            if (s + u + 1 < nslab) lstore((u + 1) & 1, (u + 1) % SYRK_PF);
+            lds_barrier();
+        }
     }
     if (TOLDS) {
         // the staging buffers are dead (last barrier): the updated lower blocks become the packed image of the factorisation
@@ -926,7 +923,7 @@ __device__ __forceinline__ void syrk_diag_wave(const GemmArgs& g, double* lA, in
         loff[u] = (q >> 6) * LROW + (q & 63) * 2;
     }
     // rows [0, 16 MT) of an augmented slab: the chunks of this thread whose row pair is live
-    const bool glive = MT > 0 && ((tid & 63) * 2) < 16 * MT;
+    const bool glive = MT > 0 && tid < 128 * MT;     // one row pair of the augmented slab per thread
     const int nslab = (g.k1 - g.k0) * (GP_TS / KS);
     const int fbase = (lane >> 4) * LROW + (lane & 15);
 
@@ -958,32 +955,26 @@ __device__ __forceinline__ void syrk_diag_wave(const GemmArgs& g, double* lA, in
                 }
         }
 
-        d2 ra[4], ra2[4];
-        d2 rg[4];       // augmented slab: one staging set, loaded one slab ahead (a few live rows, L2-resident)
-        auto gload = [&](int s, d2 (&xa)[4]) {
+        // staging as in syrk_chain_wave above: SYRK_PF register sets, LDS-only barriers
+        d2 rs[SYRK_PF][4], rgs[MT > 0 ? SYRK_PF : 1];
+        const int gcol = tid / (8 * (MT > 0 ? MT : 1)), grp = tid % (8 * (MT > 0 ? MT : 1));
+        auto gload = [&](int s, int set) {
             const int kk = g.k0 + (s >> 3);
             const double* pa = tref_tile(g.A, b, ti, kk) + (s & 7) * (KS * GP_TS);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xa[u] = *reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2);
-        };
-        auto gload_g = [&](int s) {
+            for (int u = 0; u < 4; ++u) rs[set][u] = *reinterpret_cast<const d2*>(pa + (tid + 256 * u) * 2);
             if (MT > 0 && glive) {
-                const int kk = g.k0 + (s >> 3);
                 const double* pg = tref_tile(g.A, b, g.short_row0, kk) + (s & 7) * (KS * GP_TS);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) rg[u] = *reinterpret_cast<const d2*>(pg + (tid + 256 * u) * 2);
+                rgs[MT > 0 ? set : 0] = *reinterpret_cast<const d2*>(pg + gcol * GP_TS + 2 * grp);
             }
         };
-        auto lstore = [&](int buf, const d2 (&xa)[4]) {
+        auto lstore = [&](int buf, int set) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(lA + buf * OPER_LDS + loff[u]) = xa[u];
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(lA + buf * OPER_LDS + loff[u]) = rs[set][u];
+            if (MT > 0 && glive)
+                *reinterpret_cast<d2*>(lG + buf * OPER_LDS + gcol * LROW + 2 * grp) = rgs[MT > 0 ? set : 0];
         };
-        auto lstore_g = [&](int buf) {
-            if (MT > 0 && glive) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(lG + buf * OPER_LDS + loff[u]) = rg[u];
-            }
-        };
+        auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
         auto compute = [&](int buf) {
             const double* pa = lA + buf * OPER_LDS + fbase;
             const double* pg = lG + buf * OPER_LDS + fbase;
@@ -1009,24 +1000,18 @@ __device__ __forceinline__ void syrk_diag_wave(const GemmArgs& g, double* lA, in
             }
         };
         if (nslab > 0) {
-            gload(0, ra);
-            gload_g(0);
-            lstore(0, ra);
-            lstore_g(0);
-            gload(1, ra);
-            __syncthreads();
-            for (int s = 0; s < nslab; s += 2) {
-                if (s + 2 < nslab) gload(s + 2, ra2);
-                gload_g(s + 1);
-                compute(0);
-                lstore(1, ra);
-                lstore_g(1);
-                __syncthreads();
-                if (s + 3 < nslab) gload(s + 3, ra);
-                if (s + 2 < nslab) gload_g(s + 2);
-                compute(1);
-                if (s + 2 < nslab) { lstore(0, ra2); lstore_g(0); }
-                __syncthreads();
+#pragma unroll
+            for (int u = 0; u < SYRK_PF; ++u) gload(u, u);          // nslab is a multiple of 8 >= SYRK_PF
+            lstore(0, 0);
+            lds_barrier();
+            for (int s = 0; s < nslab; s += SYRK_PF) {
+#pragma unroll
+                for (int u = 0; u < SYRK_PF; ++u) {
+                    if (s + u + SYRK_PF < nslab) gload(s + u + SYRK_PF, u);
+                    compute(u & 1);
+                    if (s + u + 1 < nslab) lstore((u + 1) & 1, (u + 1) % SYRK_PF);
+                    lds_barrier();
+                }
             }
         }
 #pragma unroll
