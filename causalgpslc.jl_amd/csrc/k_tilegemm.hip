@@ -48,6 +48,12 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // staging instructions.  Measured (profiles/r04_ab_experiments.md §11, three alternating pairs): trailing update 66.4 ->
 // 67.2 TFLOP/s, unit A +0.55 %; priority 3 the same; on the strip kernel -0.3 % (its second phase wants the partner's
 // staging to proceed) -> applied to tile_gemm_nt_kernel only.
+// K-loop barriers of the trailing and strip kernels order LDS traffic only: __syncthreads() carries a fence that also waits
+// vmcnt(0), i.e. for the slab requested at the top of the iteration — the register staging then ran ONE slab ahead, not two.
+// The barrier needs exactly two things, both LDS: this wave's ds_writes of the next slab have landed (lgkmcnt(0)) and every
+// wave has issued the MFMAs that consumed its ds_reads of the buffer about to be overwritten (program order before s_barrier).
+// Measured (profiles/r04_ab_experiments.md §13): trailing update 66.9 -> 67.2 TFLOP/s, unit A +0.3 %, N = 1024 0..+1.7 %.
+#define KLOOP_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define MFMA_PRIO_UP __builtin_amdgcn_s_setprio(1)
 #define MFMA_PRIO_DOWN __builtin_amdgcn_s_setprio(0)
 
@@ -294,13 +300,13 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
                     if (ACC) compute(0, s); else compute_p(0, s);
                     MFMA_PRIO_DOWN;
                     lstore(1, ra, rb);
-                    __syncthreads();
+                    KLOOP_BARRIER;
                     if (s + 3 < nslab) gload(s + 3, ra, rb);
                     MFMA_PRIO_UP;
                     if (ACC) compute(1, s + 1); else compute_p(1, s + 1);
                     MFMA_PRIO_DOWN;
                     if (s + 2 < nslab) lstore(0, ra2, rb2);
-                    __syncthreads();
+                    KLOOP_BARRIER;
                 }
             } else {   // timing-only diagnostic: same MFMA / ds_read stream, operand traffic removed
                 for (int s = 0; s < nslab; s += 2) {
@@ -476,11 +482,11 @@ __device__ __forceinline__ void strip_item(const GemmArgs& g, const int b, const
             if (s + 2 < nslab) gload(s + 2, ra2, rb2);
             compute(0);
             lstore(1, ra, rb);
-            __syncthreads();
+            KLOOP_BARRIER;
             if (s + 3 < nslab) gload(s + 3, ra, rb);
             compute(1);
             if (s + 2 < nslab) lstore(0, ra2, rb2);
-            __syncthreads();
+            KLOOP_BARRIER;
         }
     }
     if (GP_DBG_ON(g)) st2 = __builtin_amdgcn_s_memtime();
