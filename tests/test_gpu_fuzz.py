@@ -94,3 +94,37 @@ def test_results_are_bitwise_reproducible(gp):
             assert np.array_equal(x, y)
     lp1, lp2 = gp.yLogpdf(g), gp.yLogpdf(g)
     assert np.array_equal(lp1, lp2)
+
+
+@pytest.mark.parametrize("L", [15, 16, 31, 32, 33, 64, 126, 127, 128])
+@pytest.mark.parametrize("n,binary", [(385, False), (300, True)])
+def test_level_count_boundaries(gp, L, n, binary):
+    """The number of right-hand sides (L + 1) switches code paths at 16 / 17 (one or two 16-row blocks of augmented rows
+    riding with the diagonal items), 32 / 33 (augmented tiles as ordinary short items; only the live 32 rows written below
+    that), and 127 / 128 (one augmented tile row: the epilogue sums z.w / w.w from the rows of R and the augmented diagonal
+    tile is never updated — two tile rows: the Schur block as before).  Several tiles per side so that the in-panel chain
+    (folded diagonal tile, strip kernel) runs.  Every level's SATE, MeanITE at the first and the last level."""
+    rng = np.random.default_rng(5000 + L + n)
+    nU, nX, S = 2, 3, 2
+    X = rng.standard_normal((n, nX))
+    T = (rng.random(n) < 0.5).astype(float) if binary else rng.standard_normal(n)
+    Y = np.sin(T) + 0.4 * X[:, 0] + 0.3 * rng.standard_normal(n)
+    ig = lambda size: np.maximum(4.0 / rng.gamma(4.0, 1.0, size=size), 0.3)   # noqa: E731
+    U = rng.standard_normal((n, nU, S))
+    uyLS, xyLS = ig((nU, S)), ig((nX, S))
+    tyLS, yNoise, yScale = ig(S), ig(S), ig(S)
+    doTs = np.linspace(-1.5, 1.5, L)
+    if binary:
+        doTs[0], doTs[-1] = 0.0, 1.0
+    g = gp.GPSLCObject(X, T, Y, U, uyLS, xyLS, tyLS, yNoise, yScale)
+    ms, vs, mi = gp.predict(g, doTs, want_mean_ite=True)
+    lp = gp.yLogpdf(g)
+    for s in range(S):
+        p = orc.PosteriorSample(uyLS[:, s], xyLS[:, s], float(tyLS[s]), float(yNoise[s]), float(yScale[s]), U[:, :, s])
+        rm, rv, logdet, quad = orc.structured_sate(p, X, T, Y, doTs)
+        assert np.all(np.abs(ms[s] - rm) <= 1e-9 * np.abs(rm) + 1e-13), (L, n, s)
+        assert np.all(np.abs(vs[s] - rv) <= 1e-8 * np.abs(rv) + 1e-12 * p.yScale), (L, n, s)
+        assert abs(lp[s] - (-0.5 * (n * np.log(2 * np.pi) + logdet + quad))) <= 1e-10 * abs(lp[s]) + 1e-10
+        for l in (0, L - 1):
+            m, _ = orc.structured_ite(p, X, T, Y, doTs[l])
+            assert np.max(np.abs(mi[:, s, l] - m)) <= 1e-9 * np.max(np.abs(m)) + 1e-13, (L, n, s, l)
