@@ -180,6 +180,13 @@ def cpu_baseline(n, D, K, units, X, T, Y, post, doT):
                                    post["U"][:, :, s] if K else None)
     ref = []
     unit0 = None
+    # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers: under --gpus N the BLAS pool would be one thread.  Give the
+    # CPU leg the pool an N = 1 run gets (OpenBLAS caps it at its build's 64), for the duration of the leg only.
+    try:
+        from threadpoolctl import threadpool_limits
+        pool = threadpool_limits(limits=min(64, os.cpu_count() or 1), user_api="blas")
+    except Exception:
+        pool = None
     t0 = time.perf_counter()
     for s in range(units):
         M, Cv = orc.ite_distributions([sample(s)], X, T, Y, doT)
@@ -194,6 +201,8 @@ def cpu_baseline(n, D, K, units, X, T, Y, post, doT):
         orc.structured_sate(sample(s), X, T, Y, np.array([doT]))
     dts = time.perf_counter() - t1
     thr, blas = blas_info()
+    if pool is not None:
+        pool.restore_original_limits()
     rec = {"value": units / dt, "unit": "posterior samples/s", "cores": thr, "kind": "port",
            "sample": f"{units} (sample, level) units at N={n} D={D} nU={K}: literal restatement of the reference "
                      f"algorithm (5 kernel builds, 3 symmetric-indefinite solves, 4 GEMMs; NumPy/SciPy on {blas}), "
