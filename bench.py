@@ -180,13 +180,6 @@ def cpu_baseline(n, D, K, units, X, T, Y, post, doT):
                                    post["U"][:, :, s] if K else None)
     ref = []
     unit0 = None
-    # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers: under --gpus N the BLAS pool would be one thread.  Give the
-    # CPU leg the pool an N = 1 run gets (OpenBLAS caps it at its build's 64), for the duration of the leg only.
-    try:
-        from threadpoolctl import threadpool_limits
-        pool = threadpool_limits(limits=min(64, os.cpu_count() or 1), user_api="blas")
-    except Exception:
-        pool = None
     t0 = time.perf_counter()
     for s in range(units):
         M, Cv = orc.ite_distributions([sample(s)], X, T, Y, doT)
@@ -201,8 +194,6 @@ def cpu_baseline(n, D, K, units, X, T, Y, post, doT):
         orc.structured_sate(sample(s), X, T, Y, np.array([doT]))
     dts = time.perf_counter() - t1
     thr, blas = blas_info()
-    if pool is not None:
-        pool.restore_original_limits()
     rec = {"value": units / dt, "unit": "posterior samples/s", "cores": thr, "kind": "port",
            "sample": f"{units} (sample, level) units at N={n} D={D} nU={K}: literal restatement of the reference "
                      f"algorithm (5 kernel builds, 3 symmetric-indefinite solves, 4 GEMMs; NumPy/SciPy on {blas}), "
@@ -452,12 +443,19 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and rank == 0 and not a.no_cpu_baseline:
+        # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers; rank 0 also runs the CPU leg, whose BLAS pool should be
+        # the one an N = 1 run gets.  Set before NumPy / SciPy load their OpenBLAS (raising the pool afterwards through
+        # threadpoolctl crashed the bundled OpenBLAS on the GPU box).
+        for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+            os.environ[k] = str(min(64, os.cpu_count() or 1))
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # functional rehearsal of the N > 1 path on a one-GPU box: every rank uses device 0 and the process
     # group is gloo (RCCL refuses two ranks on one device); never used for reported numbers
