@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, call 18: trailing kernel with a condition-free K loop instantiated for full tiles (no EXEC-masked branches around the
 # MFMA groups) against the single loop of round 3: parity, then N = 4096 (L = 1 and the 64-level region) and N = 2048
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r04_19
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r04_18
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 timeout -k 10 800 python3 -m pytest tests/test_gpu_estimation.py tests/test_gpu_fullsize.py tests/test_gpu_fuzz.py -m gpu -x -q > $OUT/tests.log 2>&1
@@ -16,7 +16,7 @@ d=json.loads(open('$OUT/c.json').read().strip().splitlines()[-1]); r=d['roofline
 }
 for rep in 1 2 3; do
 run "N=4096 base" --lib $L/libgpslc_hip_var_base.so
-run "N=4096 FULLONLY kernel"
+run "N=4096 full-tile loop (second K-loop instantiation in the same kernel)"
 done
 run "N=2048 base" --lib $L/libgpslc_hip_var_base.so --n 2048 --samples-per-step 4096 --no-config4
-run "N=2048 FULLONLY kernel" --n 2048 --samples-per-step 4096 --no-config4
+run "N=2048 full-tile loop (second K-loop instantiation in the same kernel)" --n 2048 --samples-per-step 4096 --no-config4

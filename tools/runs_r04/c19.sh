@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call 18: trailing kernel with a condition-free K loop instantiated for full tiles (no EXEC-masked branches around the
+# round 4, call 19: trailing kernel as a separate FULLONLY instantiation (no general path at all) against the single loop of round 3
 # MFMA groups) against the single loop of round 3: parity, then N = 4096 (L = 1 and the 64-level region) and N = 2048
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r04_19
 mkdir -p $OUT
