@@ -539,8 +539,10 @@ int auto_batch(gpslc_ctx* c, int64_t S, size_t per_sample_bytes, size_t fixed_by
     // enough matrices in flight that the per-step diagonal-block kernel (one workgroup per matrix) and the
     // launch quantisation of the late, small trailing updates are amortised: 1024 at N = 4096 (82 GB of the
     // 288 GB; measured 2013 / 2040 / 2055 / 2064 samples/s at batch 256 / 512 / 1024 / 2048)
+    // small matrices: up to 16,384 per chunk (N = 1024: 4,096 / 8,192 / 16,384 per chunk -> 83.8 k / 84.6 k / 86.5 k samples/s,
+    // profiles/r04_ab_experiments.md §16 — every launch's ramp and tail are amortised over more items); memory permitting
     long long b = 1048576LL / ((long long)c->nt * c->nt);
-    b = std::max<long long>(32, std::min<long long>(b, 4096));
+    b = std::max<long long>(32, std::min<long long>(b, 16384));
     if (c->max_batch > 0) b = c->max_batch;
     size_t free_b = 0, tot_b = 0;
     HC(hipMemGetInfo(&free_b, &tot_b));
