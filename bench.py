@@ -48,7 +48,7 @@ HBM_PEAK_GBPS = 8000.0
 # pure fp64 VALU issue time per posterior sample at N=4096 D=8 nU=2, 2.4 GHz: SQ_ACTIVE_INST_VALU x 4 clocks / 1024 SIMDs per
 # 1,024-sample launch (profiles/r04_pmc_gram.md, r04_pmc_ite_mean.md — unchanged since round 3; round 2: 18.6 and 31.4 — table-driven exp, and the
 # MeanITE pass lost one of its two exp per pair)
-C2_HBM_BYTES_PER_SAMPLE = 39.6e6      # profiles/r04_pmc_n1024_per_kernel.md (re-measured when the schedule changes)
+C2_HBM_BYTES_PER_SAMPLE = 38.6e6      # profiles/r04_pmc_n1024_per_kernel.md (re-measured when the schedule changes)
 GRAM_VALU_US_N4096 = 17.4
 ITE_MEAN_VALU_US_N4096 = 19.1
 KERNEL_SRC = os.path.join(ROOT, "causalgpslc.jl_amd", "csrc", "k_tilegemm.hip")

@@ -32,8 +32,8 @@ $KS $OUT/trace "rocprofv3 --kernel-trace --stats of \`python3 bench.py --steps 3
 $KS $OUT/trace_b "rocprofv3 --kernel-trace --stats of \`python3 tools/bench_unit_b.py 4096 64 1 10\` (2 x 64 (sample, level) units of B + C at N=4096: warm-up call + timed call, 10 draws per unit)" 0 > $OUT/kernel_stats_unit_b.md
 $KS $OUT/trace_c2 "rocprofv3 --kernel-trace --stats of the unit-A bench at BASELINE config 2 (N=1024 D=4 nU=1, 4 x 8192 posterior samples: 1 warm-up + 3 timed steps)" 32768 > $OUT/kernel_stats_c2.md
 $KS $OUT/trace_c2l "rocprofv3 --kernel-trace --stats of BASELINE config 2 as stated (N=1024 D=4 nU=1, ONE gpslc_predict_dev call with S = 1000 per step; 4 calls: 1 warm-up + 3 timed): kernel launches per call = calls / 4" 4000 > $OUT/kernel_stats_c2_literal.md
-{ echo "## HBM traffic per kernel at BASELINE config 2 (N = 1024, D 4, nU 1; a launch = one chunk of 4,096 posterior samples)"; echo;
-for k in tile_fused_strip_kernel tile_syrk_diag_kernel gram_kernel diag_potrf_inv_v2_kernel ite_mean_kernel backsolve_update_kernel "tile_gemm_nt_kernel<0, 0>" rhs_tiles_kernel backsolve_alpha_kernel; do
+{ echo "## HBM traffic per kernel at BASELINE config 2 (N = 1024, D 4, nU 1; a launch = one chunk of 8,192 posterior samples)"; echo;
+for k in tile_fused_strip_kernel diag_update_potrf_kernel gram_kernel diag_potrf_inv_v2_kernel ite_mean_kernel backsolve_update_kernel "tile_gemm_nt_kernel<0, 0>" rhs_tiles_kernel backsolve_alpha_kernel; do
   echo "### $k"; $PS $OUT/c2pmc "$k" | tail -2; echo; done; } > $OUT/pmc_c2_per_kernel.md
 rm -rf $OUT/c2pmc $OUT/trace $OUT/trace_b $OUT/trace_c2 $OUT/trace_c2l
 head -22 $OUT/kernel_stats.md; head -8 $OUT/kernel_stats_c2_literal.md
