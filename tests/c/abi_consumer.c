@@ -4,7 +4,9 @@
  *       logdet = (n - 1) log(noise) + log(noise + n scale)
  *       x' C^-1 x = x'x / noise - scale (sum x)^2 / (noise (noise + n scale))          (Sherman-Morrison)
  * through gpslc_gp_logpdf (S parameter sets), gpslc_nodes_logpdf (heterogeneous nodes) and, for n large enough to
- * leave the single-workgroup kernels, the tiled path.  Exit code 0 = all within 1e-10 relative. */
+ * leave the single-workgroup kernels, the tiled path; then the ensemble driver (gpslc_set_data, gpslc_predict,
+ * gpslc_set_ensemble): the reference's exact-zero identities at n = 300 and the placement of a sample in an ensemble.
+ * Exit code 0 = all within 1e-10 relative (exact where stated). */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -71,6 +73,55 @@ int main(void) {
         st = gpslc_gp_logpdf(ctx, 1, 0, NULL, 1, NULL, &sc1, &nneg, x, 1, out);
         if (st <= 0) { printf("expected a positive info for a non-PD matrix, got %d\n", st); ++bad; }
         free(x);
+        gpslc_destroy(ctx);
+    }
+    /* (e) the ensemble driver from plain C: gpslc_set_data + gpslc_predict on a 300-instance data set (three tiles per side).
+     *   - every treatment equal to the intervention level: MeanSATE, MeanITE exactly 0, VarSATE exactly pred_noise / n
+     *     (test/estimation.jl:6-136 of the reference, at n > 1);
+     *   - gpslc_set_ensemble: sample 1 of a 3-sample ensemble predicted on its own draws the normals the 3-sample call
+     *     draws for it (bit for bit). */
+    {
+        const int n = 300, nX = 2, nU = 1, S = 3, L = 2, spp = 2;
+        gpslc_ctx* ctx = NULL;
+        if (gpslc_create(&ctx, 0, n, nX, nU, GPSLC_FLAG_DEFAULT) != GPSLC_OK) { printf("gpslc_create (predict) failed\n"); return 6; }
+        double* X = (double*)malloc(sizeof(double) * n * nX);
+        double* T = (double*)malloc(sizeof(double) * n);
+        double* Y = (double*)malloc(sizeof(double) * n);
+        double* U = (double*)malloc(sizeof(double) * n * nU * S);
+        for (int i = 0; i < n; ++i) {
+            X[i] = sin(0.11 * i); X[n + i] = cos(0.07 * i);
+            T[i] = 0.75; Y[i] = sin(0.3 * i) + 0.2 * X[i];
+            for (int s = 0; s < S; ++s) U[i + n * s] = cos(0.05 * (i / 10) + s);
+        }
+        const double uyLS[3] = {1.1, 0.9, 1.4}, xyLS[6] = {1.0, 1.3, 0.8, 1.2, 1.5, 0.7}, tyLS[3] = {1.0, 1.2, 0.9};
+        const double yScale[3] = {1.0, 0.8, 1.3}, yNoise[3] = {0.5, 0.7, 0.4};
+        const double doT[2] = {0.75, 0.1}, pn = 1e-10;
+        int st = gpslc_set_data(ctx, X, T, Y);
+        if (st != GPSLC_OK) { printf("gpslc_set_data: %d\n", st); return 6; }
+        double mS[6], vS[6];
+        double* mI = (double*)malloc(sizeof(double) * n * S * L);
+        double* dr = (double*)malloc(sizeof(double) * L * n * S * spp);
+        st = gpslc_predict(ctx, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, pn, spp, 5, NULL, mS, vS, mI, dr);
+        if (st != GPSLC_OK) { printf("gpslc_predict: status %d (%s)\n", st, gpslc_last_error(ctx)); return 6; }
+        for (int s = 0; s < S; ++s) {     /* level 0 == every T: exact zeros; element (s, l) at s + S*l */
+            if (mS[s] != 0.0 || vS[s] != (n * pn) / ((double)n * (double)n)) { printf("exact-zero identity broken for sample %d: %.17g %.17g\n", s, mS[s], vS[s]); ++bad; }
+            for (int i = 0; i < n; ++i) if (mI[i + n * s] != 0.0) { printf("MeanITE not exactly 0 at (%d, %d)\n", i, s); ++bad; break; }
+            if (!(mS[s + S] != 0.0) || !(vS[s + S] > 0.0)) { printf("level 1 degenerate for sample %d\n", s); ++bad; }
+        }
+        /* sample 1 alone, placed at offset 1 of an ensemble of 3 */
+        double m1[2], v1[2];
+        double* d1 = (double*)malloc(sizeof(double) * L * n * spp);
+        if (gpslc_set_ensemble(ctx, 1, 3) != GPSLC_OK) { printf("gpslc_set_ensemble failed\n"); ++bad; }
+        st = gpslc_predict(ctx, 1, U + (size_t)n * nU, uyLS + 1, xyLS + 2, tyLS + 1, yScale + 1, yNoise + 1, L, doT, pn, spp, 5, NULL,
+                           m1, v1, NULL, d1);
+        if (st != GPSLC_OK) { printf("gpslc_predict (one sample): status %d (%s)\n", st, gpslc_last_error(ctx)); return 6; }
+        if (m1[0] != mS[1] || m1[1] != mS[1 + S] || v1[1] != vS[1 + S]) { printf("one-sample SATE differs from the ensemble's\n"); ++bad; }
+        /* draws: L x n x (S*spp), level fastest; sample 1's columns are 1*spp .. 2*spp - 1 */
+        for (size_t e = 0; e < (size_t)L * n * spp; ++e)
+            if (d1[e] != dr[(size_t)L * n * spp * 1 + e]) { printf("placed draws differ at element %zu\n", e); ++bad; break; }
+        if (gpslc_set_ensemble(ctx, 5, 3) != -3 || gpslc_set_ensemble(ctx, 0, 0) != GPSLC_OK) { printf("gpslc_set_ensemble argument check\n"); ++bad; }
+        printf("predict from C: MeanSATE(level 1) = %.12g %.12g %.12g\n", mS[S], mS[S + 1], mS[S + 2]);
+        free(X); free(T); free(Y); free(U); free(mI); free(dr); free(d1);
         gpslc_destroy(ctx);
     }
     if (bad) printf("FAILED: %d mismatches\n", bad); else printf("ok\n");

@@ -151,7 +151,9 @@ def test_production_library_ignores_measurement_switches():
 def test_plain_c_consumer(tmp_path):
     """The ABI consumed from plain C (tests/c/abi_consumer.c, compiled with gcc against include/gpslc_hip.h and linked
     to libgpslc_hip.so): closed-form node scores at n = 150 (LDS-resident kernel), 272 (left-looking kernel) and 700
-    (tiled path), the fused node call, an argument error and a not-positive-definite matrix."""
+    (tiled path), the fused node call, an argument error and a not-positive-definite matrix; then gpslc_set_data /
+    gpslc_predict / gpslc_set_ensemble: exact zeros when every treatment equals the intervention level (n = 300) and a
+    sample predicted alone at its place in the ensemble drawing the ensemble's normals."""
     inc = os.path.join(ROOT, "include")
     libdir = os.path.join(ROOT, "causalgpslc.jl_amd", "csrc")
     exe = str(tmp_path / "abi_consumer")
