@@ -393,3 +393,30 @@ def test_ccall_arguments_follow_the_header_parameter_order_by_name():
             assert got == want, f"{name}: `{e}` is passed where the header has `{pname}`"
             seen += 1
     assert seen >= 100
+
+
+def test_shim_methods_have_the_reference_signatures():
+    """Every method of part 2 that is meant to REPLACE a reference method must have that method's positional signature — same
+    parameter types in the same order, otherwise Julia adds a new method and the reference's body keeps running — and must accept
+    the reference's keywords (it may add its own, e.g. `seed`).  The reference's signatures are interface facts read from its
+    source text into tests/golden/reference_signatures.json (tests/golden/make_reference_signatures.py)."""
+    import json
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")))
+    src = _part2()
+    types = lambda plist: [p.split("::", 1)[1].strip() if "::" in p else "Any" for p in plist]   # noqa: E731
+    for name, sigs in ref.items():
+        mine = []
+        for m in re.finditer(r"^function " + name + r"\(", src, flags=re.M):
+            i, depth = m.end(), 1
+            while depth:
+                depth += {"(": 1, ")": -1}.get(src[i], 0)
+                i += 1
+            inner = re.sub(r"\s+", " ", src[m.end():i - 1]).strip()
+            pos, _, kw = inner.partition(";")
+            mine.append(([re.sub(r"\s*=.*$", "", p).strip() for p in _split_top(pos)],
+                         [re.split(r"[:=]", k)[0].strip() for k in _split_top(kw)] if kw.strip() else []))
+        assert len(mine) == len(sigs), (name, len(mine), len(sigs))
+        for sig in sigs:
+            match = [kws for pos, kws in mine if types(pos) == types(sig["positional"])]
+            assert len(match) == 1, f"{name}{sig['positional']} ({sig['file']}) has no method with the same positional types in the shim"
+            assert set(sig["keywords"]) <= set(match[0]), (name, sig["keywords"], match[0])
