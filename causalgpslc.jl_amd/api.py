@@ -259,6 +259,22 @@ class GPSLCObject:
     def _params(self):
         return (_p(self.U), _p(self.uyLS), _p(self.xyLS), _p(self.tyLS), _p(self.yScale), _p(self.yNoise))
 
+    def ctxs(self, devices: Sequence[int]):
+        """One context per entry of ``devices`` (repeats allowed: distinct contexts on one GPU), each holding the data —
+        what ``gpslc_predict_multi`` shards the posterior samples over.  Cached per device list."""
+        key = tuple(int(d) for d in devices)
+        if not key:
+            raise AssertionError("devices must name at least one GPU")
+        cache = self.__dict__.setdefault("_multi", {})
+        if key not in cache:
+            cs = []
+            for d in key:
+                c = Context(self.getN(), self.getNX(), self.getNU(), device=d, fp32_kernel=self.fp32_kernel)
+                c.set_data(self.X, self.T, self.Y)
+                cs.append(c)
+            cache[key] = cs
+        return cache[key]
+
 
 def getN(g):
     return g.getN()
@@ -366,13 +382,14 @@ def SATEsamples(MeanSATEs, VarSATEs, nSamplesPerMixture, z=None, seed=0):
 
 
 def predict(g: GPSLCObject, doTs: Sequence[float], want_mean_ite=False, spp=0, z=None, seed=0,
-            want_draws=False):
+            want_draws=False, devices: Optional[Sequence[int]] = None):
     """The ensemble entry point (gpslc_predict): returns MeanSATE (S, L), VarSATE (S, L) and, when
-    asked, MeanITE (n, S, L) / draws (L, n, S*spp)."""
+    asked, MeanITE (n, S, L) / draws (L, n, S*spp).  ``devices`` = a list of GPU indices shards the posterior samples
+    over one context per entry through ``gpslc_predict_multi`` (same results, bit for bit)."""
     n, S = g.getN(), g.getNumPosteriorSamples()
     doTs = np.ascontiguousarray(np.atleast_1d(np.asarray(doTs, dtype=np.float64)))
     L = doTs.shape[0]
-    ctx = g.ctx()
+    ctx = g.ctx() if devices is None else g.ctxs(devices)[0]
     ms = np.empty((S, L), order="F")
     vs = np.empty((S, L), order="F")
     mi = np.empty((n, S, L), order="F") if want_mean_ite else None
@@ -382,8 +399,15 @@ def predict(g: GPSLCObject, doTs: Sequence[float], want_mean_ite=False, spp=0, z
         zz = _f(z)
         if zz.shape != (n, spp, S, L):
             raise AssertionError(f"z must be (n, spp, S, L) = {(n, spp, S, L)}, got {zz.shape}")
-    st = ctx.lib.gpslc_predict(ctx.h, S, *g._params(), L, _p(doTs), float(g.hyperparams.predictionCovarianceNoise),
-                               int(spp), int(seed), _p(zz), _p(ms), _p(vs), _p(mi), _p(dr))
+    if devices is None:
+        st = ctx.lib.gpslc_predict(ctx.h, S, *g._params(), L, _p(doTs), float(g.hyperparams.predictionCovarianceNoise),
+                                   int(spp), int(seed), _p(zz), _p(ms), _p(vs), _p(mi), _p(dr))
+    else:
+        cs = g.ctxs(devices)
+        hs = (C.c_void_p * len(cs))(*[c.h for c in cs])
+        st = ctx.lib.gpslc_predict_multi(len(cs), hs, S, *g._params(), L, _p(doTs),
+                                         float(g.hyperparams.predictionCovarianceNoise), int(spp), int(seed), _p(zz),
+                                         _p(ms), _p(vs), _p(mi), _p(dr), None)
     ctx.check(st)
     if want_draws:
         return ms, vs, mi, dr
@@ -431,9 +455,10 @@ def doTRange(minDoT, maxDoT, fidelity):
 
 
 def predictCounterfactualEffects(g: GPSLCObject, nSamplesPerMixture, fidelity=100, minDoT=None, maxDoT=None,
-                                 z=None, seed=0):
+                                 z=None, seed=0, devices: Optional[Sequence[int]] = None):
     """predictCounterfactualEffects(g, spp; fidelity, minDoT, maxDoT) -> (ite [L, n, S*spp], doTrange)
-    (src/prediction.jl:23-36).  All levels share one factorisation of A per posterior sample."""
+    (src/prediction.jl:23-36).  All levels share one factorisation of A per posterior sample; ``devices`` shards the
+    posterior samples over several GPUs (``gpslc_predict_multi``)."""
     lo = float(np.min(g.T)) if minDoT is None else float(minDoT)
     hi = float(np.max(g.T)) if maxDoT is None else float(maxDoT)
     rng = doTRange(lo, hi, fidelity)
@@ -443,7 +468,7 @@ def predictCounterfactualEffects(g: GPSLCObject, nSamplesPerMixture, fidelity=10
         L = rng.shape[0]
         zz = np.asarray(z, dtype=np.float64).reshape(L, n, nSamplesPerMixture, S, order="F")
         zz = np.transpose(zz, (1, 2, 3, 0))
-    _, _, _, dr = predict(g, rng, spp=nSamplesPerMixture, z=zz, seed=seed, want_draws=True)
+    _, _, _, dr = predict(g, rng, spp=nSamplesPerMixture, z=zz, seed=seed, want_draws=True, devices=devices)
     return dr, rng
 
 

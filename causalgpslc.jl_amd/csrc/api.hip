@@ -596,7 +596,11 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
     // draws: normals workspace of one level of the sub-batch + the level-sweep staging buffer (see the unit-B loop)
     // (per unit of the sub-batch: the staging buffer holds max(1, Bb / L) samples x L levels <= Bb pairs, or one sample's
     // L > Bb levels — sized below through the extra term)
-    const size_t draws_per = want_draws ? ((io.z ? 0 : (size_t)io.spp * n * 8 + 256) +
+    // spp <= 16: the streaming draw kernel reads the unit's normals (caller's or Philox) from an operand image of
+    // 16 Np doubles (DrawArgs::zt) instead
+    static const int draws_stream = diag_env("GPSLC_DRAWS_STREAM", 1);      // measurement switch: 0 = the LDS-staged kernel of rounds 2-4
+    const bool zimage = want_draws && io.spp <= 16 && draws_stream;
+    const size_t draws_per = want_draws ? ((zimage ? (size_t)16 * Np * 8 + 256 : (io.z ? 0 : (size_t)io.spp * n * 8 + 256)) +
                                            (L > 1 ? (size_t)io.spp * n * 8 + 256 : 0)) : 0;
     const size_t unitB_all = unitB_per + draws_per;
     const size_t dtmp_extra = (want_draws && L > Bb_target) ? (size_t)(L - Bb_target) * io.spp * n * 8 : 0;
@@ -721,7 +725,8 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
             const int gs_max = std::max(1, Bb / lc_max);          // samples per sub-batch
             // draws: the library's own normals of one sub-batch (generated once per unit), and for a level sweep the
             // staging buffer [sample][level][d][i] that is rearranged into the level-fastest tensor sample group by group
-            double* zgen = (want_draws && !io.z) ? ar.take<double>((size_t)Bb * io.spp * n) : nullptr;
+            double* zgen = (want_draws && !io.z && !zimage) ? ar.take<double>((size_t)Bb * io.spp * n) : nullptr;
+            double* zt = zimage ? ar.take<double>((size_t)Bb * 16 * Np) : nullptr;
             double* dtmp = (want_draws && L > 1) ? ar.take<double>((size_t)gs_max * L * io.spp * n) : nullptr;
             const long long wbs = (long long)nt * nt * GP_TSQ, cbs = nlow * GP_TSQ;
             for (int g0 = 0; g0 < nb; g0 += gs_max) {
@@ -796,7 +801,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                         potrf_tiles(c, Cm, nt, nt, nullptr, 0, io.info + s0 + g0, n, ub, st, 0, 3, /*robust=*/true, /*info_div=*/lc);
                         DrawArgs dr{};
                         dr.Lc = Cm; dr.n = n; dr.nt = nt; dr.s0 = s0 + g0; dr.S = io.S; dr.l = l0; dr.lc = lc; dr.L = L;
-                        dr.spp = io.spp; dr.mean = meanITE; dr.z = io.z; dr.zgen = zgen; dr.seed = io.seed;
+                        dr.spp = io.spp; dr.mean = meanITE; dr.z = io.z; dr.zgen = zgen; dr.zt = zt; dr.seed = io.seed;
                         dr.rs0 = dr.s0 + (c->ens_S > 0 ? c->ens_off : 0); dr.rS = c->ens_S > 0 ? c->ens_S : io.S;
                         if (L == 1) {     // the reference tensor directly: n x (S*spp), instance fastest
                             dr.out = io.ite_draws;
@@ -1171,6 +1176,7 @@ static int set_data_impl(gpslc_ctx* c, const double* X, const double* T, const d
         c->binary_t = true;
         for (double t : c->hT) if (t != 0.0 && t != 1.0) { c->binary_t = false; break; }
         c->has_data = true;
+        c->ens_off = 0; c->ens_S = 0;      // a new data set starts outside any ensemble placement
         return GPSLC_OK;
     });
 }
@@ -1288,6 +1294,10 @@ static int predict_check(gpslc_ctx* c, int64_t S, const double* U, const double*
     if (L < 1) return bad_arg(c, 9, "L < 1");
     if (!doT) return bad_arg(c, 10, "doT is NULL");
     if (ite_draws && spp < 1) return bad_arg(c, 12, "spp < 1 with ite_draws requested");
+    // a placement left over from an earlier, smaller call would make the stream ids (off + s) + S_total * l of this call's last
+    // samples collide with the next level's streams: refuse instead of drawing correlated normals
+    if (c->ens_S > 0 && c->ens_off + S > c->ens_S)
+        return bad_arg(c, 2, "S exceeds the room gpslc_set_ensemble left: sample_offset + S > S_total");
     return 0;
 }
 
@@ -1350,6 +1360,115 @@ int gpslc_predict(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, 
         if (ite_draws) copy_out_large(c, ite_draws, odr, sizeof(double) * (size_t)L * n * S * spp);
         return st;
     });
+}
+
+// The sharded ensemble behind the ABI (the loop src/prediction.jl:30-33 over src/estimation.jl:78-84): contiguous
+// blocks of the posterior-sample index over the contexts, one host thread per context, data replicated (every ctx holds its own
+// copy: gpslc_set_data), no traffic between the devices while they compute.  The "gather" is each device's own device-to-host
+// copy into ITS block of the caller's arrays — nctx PCIe links in parallel, nothing funnels through one GPU.
+int gpslc_predict_multi(int32_t nctx, gpslc_ctx* const* ctxs, int64_t S, const double* U, const double* uyLS,
+                        const double* xyLS, const double* tyLS, const double* yScale, const double* yNoise, int32_t L,
+                        const double* doT, double pred_noise, int32_t spp, uint64_t seed, const double* z,
+                        double* meanSATE, double* varSATE, double* meanITE, double* ite_draws, int32_t* info_or_null) {
+    if (nctx < 1) return -1;
+    if (!ctxs) return -2;
+    for (int k = 0; k < nctx; ++k) {
+        if (!ctxs[k]) return -2;
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j] == ctxs[k]) return bad_arg(ctxs[0], 2, "the same ctx is listed twice (one ctx per shard: calls on a ctx are serialised)");
+    }
+    gpslc_ctx* c0 = ctxs[0];
+    for (int k = 1; k < nctx; ++k) {
+        if (ctxs[k]->n != c0->n || ctxs[k]->nX != c0->nX || ctxs[k]->nU != c0->nU)
+            return bad_arg(c0, 2, "the contexts differ in n / nX / nU");
+        if (!ctxs[k]->has_data) { set_err(c0, "gpslc_set_data has not been called on every ctx"); return GPSLC_ERR_NODATA; }
+    }
+    int rc0 = predict_check(c0, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, spp, ite_draws);
+    if (rc0) return rc0 < 0 && rc0 > -100 ? rc0 - 1 : rc0;      // argument numbers of THIS signature (S is #3, ...)
+    if (S == 0) { for (int k = 0; k < nctx; ++k) ctxs[k]->last_info.clear(); return GPSLC_OK; }
+    try {
+        const int64_t n = c0->n, nU = c0->nU, nX = c0->nX;
+        // placement of the whole call (ctxs[0]'s, if the caller set one: this call may itself be one node's share)
+        const int64_t base_off = c0->ens_S > 0 ? c0->ens_off : 0, total = c0->ens_S > 0 ? c0->ens_S : S;
+        struct Shard {
+            int64_t s0 = 0, Sr = 0;
+            std::vector<double> z, ms, vs, mi;     // staging where the shard's block is not contiguous in the caller's array (L > 1)
+            int rc = 0;
+            int64_t save_off = 0, save_S = 0;
+        };
+        std::vector<Shard> sh((size_t)nctx);
+        const bool use_z = z && ite_draws;
+        for (int k = 0; k < nctx; ++k) {
+            const int64_t q = S / nctx, r = S % nctx;
+            Shard& h = sh[(size_t)k];
+            h.s0 = k * q + std::min<int64_t>(k, r);
+            h.Sr = q + (k < r ? 1 : 0);
+            if (h.Sr == 0 || L == 1) continue;
+            if (use_z) {
+                h.z.resize((size_t)(n * spp * h.Sr * L));
+                for (int l = 0; l < L; ++l)
+                    memcpy(h.z.data() + (size_t)(n * spp * h.Sr) * l, z + (size_t)(n * spp) * (size_t)(h.s0 + S * l),
+                           sizeof(double) * (size_t)(n * spp * h.Sr));
+            }
+            if (meanSATE) h.ms.resize((size_t)(h.Sr * L));
+            if (varSATE) h.vs.resize((size_t)(h.Sr * L));
+            if (meanITE) h.mi.resize((size_t)(n * h.Sr * L));
+        }
+        auto work = [&](int k) {
+            Shard& h = sh[(size_t)k];
+            if (h.Sr == 0) { ctxs[k]->last_info.clear(); return; }
+            gpslc_ctx* c = ctxs[k];
+            h.save_off = c->ens_off; h.save_S = c->ens_S;
+            c->ens_off = base_off + h.s0; c->ens_S = total;
+            const bool direct = L == 1;
+            h.rc = gpslc_predict(c, h.Sr, nU ? U + (size_t)(n * nU) * h.s0 : nullptr, nU ? uyLS + (size_t)nU * h.s0 : nullptr,
+                                 nX ? xyLS + (size_t)nX * h.s0 : nullptr, tyLS + h.s0, yScale + h.s0, yNoise + h.s0, L, doT,
+                                 pred_noise, spp, seed,
+                                 !use_z ? nullptr : (direct ? z + (size_t)(n * spp) * h.s0 : h.z.data()),
+                                 !meanSATE ? nullptr : (direct ? meanSATE + h.s0 : h.ms.data()),
+                                 !varSATE ? nullptr : (direct ? varSATE + h.s0 : h.vs.data()),
+                                 !meanITE ? nullptr : (direct ? meanITE + (size_t)n * h.s0 : h.mi.data()),
+                                 // level-fastest tensor L x n x (S spp): a sample's columns are one contiguous run
+                                 !ite_draws ? nullptr : ite_draws + (size_t)L * n * spp * h.s0);
+            c->ens_off = h.save_off; c->ens_S = h.save_S;
+            if (h.rc >= 0 && !direct) {         // this shard's rows of the S x L and n x S x L arrays
+                for (int l = 0; l < L; ++l) {
+                    if (meanSATE) memcpy(meanSATE + h.s0 + S * l, h.ms.data() + h.Sr * l, sizeof(double) * h.Sr);
+                    if (varSATE) memcpy(varSATE + h.s0 + S * l, h.vs.data() + h.Sr * l, sizeof(double) * h.Sr);
+                    if (meanITE) memcpy(meanITE + (size_t)n * (size_t)(h.s0 + S * l), h.mi.data() + (size_t)(n * h.Sr) * l,
+                                        sizeof(double) * (size_t)(n * h.Sr));
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int k = 1; k < nctx; ++k) {
+            try { pool.emplace_back(work, k); }
+            catch (...) { work(k); }                 // no thread to be had: this shard runs here, in turn
+        }
+        work(0);
+        for (auto& t : pool) t.join();
+        int rc = 0;
+        for (int k = 0; k < nctx && rc == 0; ++k)
+            if (sh[(size_t)k].rc < 0) {
+                rc = sh[(size_t)k].rc;
+                if (k > 0) set_err(c0, "shard " + std::to_string(k) + " (device " + std::to_string(ctxs[k]->device) + "): " + ctxs[k]->err);
+            }
+        for (int k = 0; k < nctx && rc == 0; ++k) rc = sh[(size_t)k].rc;        // blocks are in sample order: the first failing pivot
+        if (info_or_null)
+            for (int k = 0; k < nctx; ++k) {
+                const Shard& h = sh[(size_t)k];
+                if (h.Sr == 0) continue;
+                if ((int64_t)ctxs[k]->last_info.size() == h.Sr) memcpy(info_or_null + h.s0, ctxs[k]->last_info.data(), sizeof(int32_t) * h.Sr);
+                else for (int64_t j = 0; j < h.Sr; ++j) info_or_null[h.s0 + j] = 0;
+            }
+        return rc;
+    } catch (const std::bad_alloc&) {
+        set_err(c0, "host staging allocation failed");
+        return GPSLC_ERR_NOMEM;
+    } catch (...) {
+        set_err(c0, "internal error");
+        return GPSLC_ERR_INTERNAL;
+    }
 }
 
 int gpslc_ite_distributions(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,

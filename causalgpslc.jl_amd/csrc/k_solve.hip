@@ -722,6 +722,149 @@ __global__ __launch_bounds__(256) void draws_mfma_kernel(DrawArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Round 5: the draws of a unit with spp <= 16 (the reference's default is 10) as a PURE STREAM of L_c.
+// What the LDS kernel above left on the table (4.3 of the ~6 TB/s a read-only sweep reaches on this chip): its 4 waves
+// meet at two barriers per 64 columns (one wave's late line stalls four), its work items span 1..nt tiles (the last long
+// row runs alone at the end of the launch), and the diagonal tile is read whole.  Here
+//   * the unit's normals are laid out ONCE, by draws_zstage_kernel, as the MFMA A-operand image zt: the 16-byte word of
+//     lane (lq, li) for the column groups (2m, 2m + 1) of a 32-column chunk sits at lane-contiguous addresses, so a wave
+//     fetches its z operands with four fully coalesced 1 KiB loads per chunk — no LDS, no barrier, no dependence
+//     between the waves of a workgroup (draws 10..15 and columns >= n are zeros in the image);
+//   * a workgroup owns the tile-row PAIR (nt-1-p, p): every item streams nt + 1 tiles, whatever p;
+//   * wave w reads only the columns of the diagonal tile at or left of its own 32 rows (8 (w + 1) of the 32 groups);
+//   * three register sets of 4 factor loads + 2 z loads each (16-column chunks) in rotation, the next two chunks in flight
+//     under the current chunk's MFMAs, 104 VGPRs -> four workgroups per CU; factor loads carry the non-temporal hint (each
+//     line is used exactly once).  Measured (same box, 64 units x 10 draws at N = 4096): 4.30 -> 6.04 TB/s of factor stream;
+//     32-column chunks with two sets 5.6, and the number of workgroups per CU (2 / 3 / 4) does not matter;
+// MFMA operands, accumulators and the order of the k groups along a row are those of draws_mfma_kernel<1>: the chains
+// are the same, so the draws are bit-identical (skipped groups of the diagonal tile only ever added +-0).
+// ---------------------------------------------------------------------------------------
+// index of z[column g][draw d] in a unit's operand image (16 * Np doubles)
+__host__ __device__ inline long long draws_zt_index(long long g, int d) {
+    return ((g >> 3) << 7) + ((g & 3) << 5) + ((long long)d << 1) + ((g >> 2) & 1);
+}
+
+// one thread = one 16-byte word of the image: columns g0 = 8 blk + lq and g0 + 4, draw d
+__global__ __launch_bounds__(256) void draws_zstage_kernel(DrawArgs a) {
+    const long long b = blockIdx.y, sb = b / a.lc, lb = b % a.lc;
+    const long long s = a.s0 + sb, lev = a.l + lb;
+    const long long n = a.n, Np = (long long)a.nt * GP_TS;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= Np * 8) return;
+    const int d = (int)(t & 15), lq = (int)(t >> 4) & 3;
+    const long long g0 = ((t >> 6) << 3) + lq, g1 = g0 + 4;
+    double v0 = 0.0, v1 = 0.0;
+    if (d < a.spp) {
+        if (a.z) {
+            const double* __restrict__ zu = a.z + n * a.spp * (s + a.S * lev);
+            if (g0 < n) v0 = zu[g0 + n * d];
+            if (g1 < n) v1 = zu[g1 + n * d];
+        } else {
+            const unsigned long long stream = (unsigned long long)((a.rs0 + sb) + a.rS * lev);
+            if (g0 < n) v0 = philox_normal(a.seed, stream, (unsigned long long)(g0 + n * d));
+            if (g1 < n) v1 = philox_normal(a.seed, stream, (unsigned long long)(g1 + n * d));
+        }
+    }
+    *reinterpret_cast<d2s*>(a.zt + b * Np * 16 + 2 * t) = (d2s){v0, v1};
+}
+
+// CC columns per chunk (CC / 4 k groups of the 16x16x4 MFMA), NS register sets in rotation, WPE waves per SIMD the
+// register allocation is held to
+template <int CC, int NS, int WPE>
+__global__ __launch_bounds__(256, WPE) void draws_stream_kernel(DrawArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const long long b = blockIdx.y, sb = b / a.lc, lb = b % a.lc;      // batch element = (sample, level) pair
+    const long long s = a.s0 + sb, lev = a.l + lb;
+    const long long n = a.n;
+    const long long Np = (long long)a.nt * GP_TS;
+    const double* __restrict__ zt = a.zt + b * Np * 16 + 2 * lane;
+    const int r0 = 32 * wave + 2 * li;                  // this lane's two rows inside the tile: r0, r0 + 1
+    const int p = blockIdx.x;
+    constexpr int NL = CC / 4, NZ = CC / 8;             // 16-byte factor / z loads per chunk and lane
+
+    for (int half = 0; half < 2; ++half) {
+        const int ib = half == 0 ? a.nt - 1 - p : p;
+        if (half == 1 && 2 * p == a.nt - 1) break;      // odd nt: the middle row has no partner
+        // the tiles (ib, 0..ib) of a row are contiguous in both tile layouts
+        const double* __restrict__ Lrow = tref_tile(a.Lc, b, ib, 0) + r0 + lq * GP_TS;
+        const int nch = (GP_TS / CC) * ib + (32 / CC) * wave + 32 / CC;   // chunks up to and including the wave's diagonal block
+        d4s acc0 = (d4s){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+        d2s lv[NS][NL], zv[NS][NZ];
+        auto load = [&](int c, d2s (&l)[NL], d2s (&z)[NZ]) {
+            c = min(c, nch - 1);                         // past the end: the last chunk again (keeps the loop body branch-free)
+            const double* __restrict__ zp = zt + (long long)c * (CC * 16);
+#pragma unroll
+            for (int m = 0; m < NZ; ++m) z[m] = *reinterpret_cast<const d2s*>(zp + m * 128);
+            const double* __restrict__ lp = Lrow + (long long)c * (CC * GP_TS);
+#pragma unroll
+            for (int kk = 0; kk < NL; ++kk)
+                l[kk] = __builtin_nontemporal_load(reinterpret_cast<const d2s*>(lp + kk * 4 * GP_TS));
+        };
+        auto compute = [&](const d2s (&l)[NL], const d2s (&z)[NZ]) {
+#pragma unroll
+            for (int kk = 0; kk < NL; ++kk) {
+                const double zf = (kk & 1) ? z[kk >> 1].y : z[kk >> 1].x;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, l[kk].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, l[kk].y, acc1, 0, 0, 0);
+            }
+        };
+        // the chunks of the wave's own 32 x 32 diagonal block: only the lower triangle belongs to L_c
+        auto mask_diag = [&](d2s (&l)[NL], int c) {
+            const int cb = (c * CC) & 31;                // first column of the chunk relative to the wave's first row
+#pragma unroll
+            for (int kk = 0; kk < NL; ++kk) {
+                const int cc = cb + 4 * kk + lq;
+                if (cc > 2 * li) l[kk].x = 0.0;
+                if (cc > 2 * li + 1) l[kk].y = 0.0;
+            }
+        };
+        constexpr int ND = 32 / CC;                      // chunks of the diagonal block (1 or 2)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) load(i, lv[i], zv[i]);
+        int c = 0;
+        for (; c + NS + ND - 1 < nch; c += NS) {         // chunks c .. c + NS - 1 are all left of the diagonal block
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                compute(lv[i], zv[i]);
+                load(c + NS + i, lv[i], zv[i]);
+            }
+        }
+        const int rem = nch - c;                         // ND .. NS + ND - 1 chunks left; the first min(rem, NS) are loaded
+#pragma unroll
+        for (int i = 0; i < NS + ND - 1; ++i) {
+            if (i < rem) {
+                if (i >= NS) load(c + i, lv[i % NS], zv[i % NS]);
+                if (i >= rem - ND) mask_diag(lv[i % NS], c + i);
+                compute(lv[i % NS], zv[i % NS]);
+            }
+        }
+        // acc{0,1}[v]: row r0 + {0,1}, draw 4 v + lq
+        const long long gi = (long long)ib * GP_TS + r0;
+        if (gi < n) {
+            const double mu0 = a.mean[gi + n * (s + a.S * lev)];
+            const double mu1 = (gi + 1 < n) ? a.mean[gi + 1 + n * (s + a.S * lev)] : 0.0;
+            double* __restrict__ ob = a.out + a.obase + sb * a.osb + lb * a.osl + gi * a.osi;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int dd = 4 * v + lq;
+                if (dd < a.spp) {
+                    double* o = ob + (long long)dd * a.osd;
+                    const double x0 = mu0 + acc0[v], x1 = mu1 + acc1[v];
+                    if (a.osi == 1 && gi + 1 < n && ((reinterpret_cast<unsigned long long>(o) & 15ull) == 0)) {
+                        *reinterpret_cast<d2s*>(o) = (d2s){x0, x1};
+                    } else {
+                        o[0] = x0;
+                        if (gi + 1 < n) o[a.osi] = x1;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Level sweep (L > 1): the draws of the sub-batch are produced level by level into tmp[b][l][d][i] (instance
 // fastest: coalesced stores) and rearranged ONCE into the reference's level-fastest tensor
 // ite[l + L*(i + n*(s*spp + d))] (src/prediction.jl:30-33) through LDS, so that both the reads (1 KiB runs along i)
@@ -759,6 +902,36 @@ static void launch_draws_t(const DrawArgs& a, int nbatch, hipStream_t st) {
     hipLaunchKernelGGL((draws_mfma_kernel<NQ>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
 }
 void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st) {
+    if (a.spp <= 16 && a.zt) {     // one MFMA pass wide: the barrier-free stream of L_c (round 5)
+        const long long words = (long long)a.nt * GP_TS * 8;
+        hipLaunchKernelGGL(draws_zstage_kernel, dim3((unsigned)((words + 255) / 256), nbatch), dim3(256), 0, st, a);
+        const dim3 grid((a.nt + 1) / 2, nbatch);
+#ifdef GPSLC_DIAG
+        // measurement build: GPSLC_DRAWS_VAR picks the register-set arrangement, GPSLC_DRAWS_LDS pads the workgroup's LDS
+        // allocation (KiB) to pin the number of workgroups per CU
+        static const int var = diag_env("GPSLC_DRAWS_VAR", 0);
+        static const int pad = diag_env("GPSLC_DRAWS_LDS", 0) * 1024;
+        auto go = [&](auto kern) {
+            if (pad > 0) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+            hipLaunchKernelGGL(kern, grid, dim3(256), pad, st, a);
+        };
+        // round 5, one box (profiles/r05_ab_experiments.md §1), TB/s of factor stream at N = 4096, 64 units x 10 draws:
+        //   <32,2,2> 5.62-5.65   <32,2,3> 5.59   <32,3,2> 5.55   <16,4,3> 5.60   <16,4,4> 6.02   <16,3,4> 6.04 (production)
+        if (var == 2) { go(draws_stream_kernel<16, 4, 4>); return; }
+        if (var == 3) { go(draws_stream_kernel<32, 2, 3>); return; }
+        if (var == 4) { go(draws_stream_kernel<16, 4, 3>); return; }
+        if (var == 5) { go(draws_stream_kernel<32, 3, 2>); return; }
+        if (var == 6) { go(draws_stream_kernel<32, 2, 2>); return; }
+        if (var == 7) { go(draws_stream_kernel<8, 4, 4>); return; }
+        if (var == 8) { go(draws_stream_kernel<8, 6, 4>); return; }
+        if (var == 9) { go(draws_stream_kernel<16, 2, 4>); return; }
+        if (var == 10) { go(draws_stream_kernel<16, 3, 5>); return; }
+        if (var == 11) { go(draws_stream_kernel<8, 4, 6>); return; }
+        if (var != 0 || pad > 0) { go(draws_stream_kernel<16, 3, 4>); return; }
+#endif
+        hipLaunchKernelGGL((draws_stream_kernel<16, 3, 4>), grid, dim3(256), 0, st, a);
+        return;
+    }
     if (!a.z) {     // the library's own stream: every normal of the unit is generated exactly once
         const long long pairs = ((long long)a.n * a.spp + 1) / 2;
         hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((pairs + 255) / 256), nbatch), dim3(256), 0, st, a.seed, a.rs0,

@@ -197,6 +197,24 @@ int gpslc_predict_dev(gpslc_ctx* ctx, int64_t S, const double* U, const double* 
                       int32_t spp, uint64_t seed, const double* z_or_null,
                       double* meanSATE, double* varSATE, double* meanITE, double* ite_draws);
 
+/* The same call sharded over several GPUs of one node: what the loop of predictCounterfactualEffects (src/prediction.jl:30-33)
+ * over the posterior samples (src/estimation.jl:78-84) becomes when the ensemble is partitioned.  ctxs[0..nctx) are
+ * DISTINCT contexts created with the same (n, nX, nU), one per device (gpslc_create(&ctx_k, device_k, ...)), each holding the data
+ * (gpslc_set_data on every one: X, T, Y are replicated, N (D + 2) doubles).  Context k computes the contiguous block
+ * [k q + min(k, r), ...) of q = S / nctx (+ 1 for k < r = S mod nctx) posterior samples on its own host thread and its own device;
+ * nothing moves between the devices while they compute, and every device copies its block of each result straight into the
+ * caller's HOST arrays (the same arrays, layouts and NULL conventions as gpslc_predict).  The library's normals are placed with
+ * gpslc_set_ensemble semantics, so seeded draws — like every other output — are bit-identical to ONE gpslc_predict call over all S
+ * samples, whatever nctx (several contexts on one device are allowed: that is how the single-GPU tests check it).  A placement set on
+ * ctxs[0] beforehand is honoured as the placement of the whole call (one node's share of a larger ensemble).
+ * info_or_null (S): the 1-based failing pivot of every sample as gpslc_last_info reports it.  Returns the first negative status of
+ * any shard, else the first failing pivot in sample order, else 0; gpslc_last_error(ctxs[0]) names the shard.  Host pointers only. */
+int gpslc_predict_multi(int32_t nctx, gpslc_ctx* const* ctxs, int64_t S, const double* U, const double* uyLS,
+                        const double* xyLS, const double* tyLS, const double* yScale, const double* yNoise,
+                        int32_t L, const double* doT, double pred_noise, int32_t spp, uint64_t seed,
+                        const double* z_or_null, double* meanSATE, double* varSATE, double* meanITE,
+                        double* ite_draws, int32_t* info_or_null);
+
 /* ITEDistributions(g, doT) (src/estimation.jl:66-86) for one intervention level, with the
  * reference's output layout: MeanITEs S x n and CovITEs S x n x n, sample index fastest;
  * CovITEs carries the + pred_noise*I of src/estimation.jl:82.  Either output may be NULL. */

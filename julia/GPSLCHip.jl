@@ -234,6 +234,29 @@ function predict(c::Ctx, p::Pack, doT::Vector{Float64}, pred_noise::Float64; spp
     mS, vS, mI, dr
 end
 
+"""`predict` sharded over several GPUs of one node — `cs` = one context per device (`Ctx(n, nX, nU; device=k)`, each with
+the data: `set_data!` on every one), the posterior samples split into contiguous blocks, one host thread per context inside the
+library, every device copying its block of the results into these host arrays.  Same results as `predict(cs[1], …)` over all S
+samples, bit for bit, seeded draws included.  Returns (meanSATE, varSATE, meanITE | nothing, ite | nothing, info)."""
+function predict_multi(cs::Vector{Ctx}, p::Pack, doT::Vector{Float64}, pred_noise::Float64; spp::Integer=0, seed::Integer=0,
+                       z=nothing, want_mean_ite::Bool=false, want_draws::Bool=false)
+    S, L, n = length(p.tyLS), length(doT), cs[1].n
+    mS, vS = Matrix{Float64}(undef, S, L), Matrix{Float64}(undef, S, L)
+    mI = want_mean_ite ? Array{Float64}(undef, n, S, L) : nothing
+    dr = want_draws ? Array{Float64}(undef, L, n, S * spp) : nothing
+    info = Vector{Int32}(undef, S)
+    zf = f64(z)
+    ctxs = Ptr{Cvoid}[c.h for c in cs]
+    GC.@preserve cs ctxs p doT zf mS vS mI dr info check(cs[1], ccall((:gpslc_predict_multi, lib), Cint,
+        (Int32, Ptr{Ptr{Cvoid}}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Int32, Ptr{Float64}, Float64, Int32, UInt64, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+        length(ctxs), pointer(ctxs), S, ptr(p.U), ptr(p.uyLS), ptr(p.xyLS), pointer(p.tyLS), pointer(p.yScale), pointer(p.yNoise),
+        L, pointer(doT), pred_noise, spp, seed, ptr(zf),
+        pointer(mS), pointer(vS), ptr(mI), ptr(dr), pointer(info)))
+    mS, vS, mI, dr, info
+end
+
 """As `predict`, every array argument a DEVICE pointer (ROCArray memory); outputs stay in HBM."""
 predict_dev(c::Ctx, S::Integer, U::Ptr{Float64}, uyLS::Ptr{Float64}, xyLS::Ptr{Float64}, tyLS::Ptr{Float64},
             yScale::Ptr{Float64}, yNoise::Ptr{Float64}, L::Integer, doT::Ptr{Float64}, pred_noise::Float64,
@@ -376,19 +399,24 @@ end
 """dctx(n, nX, nU): a context of that shape, re-used across calls (the data set is handed over again by the caller with
 `set_data!`: n (nX + 2) doubles).  The reference's parameter-level functions — conditionalITE(uyLS, …, U, X, T, Y, doT),
 likelihoodDistribution — carry their data in the arguments and are called in loops (src/estimation.jl:78-84): a context
-per call would put hipMalloc + stream creation inside that loop.  At most 8 shapes are kept."""
+per call would put hipMalloc + stream creation inside that loop.  At most 8 shapes are kept; the ninth evicts the ONE shape used
+longest ago (its context is left to its finalizer: a caller may still hold it)."""
 const DCTX = Dict{NTuple{3,Int},Ctx}()
+const DCTX_USED = Dict{NTuple{3,Int},Int}()          # key -> tick of its last use
+const DCTX_TICK = Ref(0)
 function dctx(n::Integer, nX::Integer, nU::Integer)
     key = (Int(n), Int(nX), Int(nU))
     c = get(DCTX, key, nothing)
     if c === nothing || c.h == C_NULL
         if length(DCTX) >= 8
-            foreach(destroy!, values(DCTX))
-            empty!(DCTX)
+            lru = argmin(DCTX_USED)
+            delete!(DCTX, lru)
+            delete!(DCTX_USED, lru)
         end
         c = Ctx(n, nX, nU)
         DCTX[key] = c
     end
+    DCTX_USED[key] = (DCTX_TICK[] += 1)
     c
 end
 
@@ -412,7 +440,11 @@ function draw(c::Ctx, F::Matrix{Float64}, ls::Vector{Float64}, scale::Float64, n
 end
 
 """log N(x; 0, covscale * cov): `cov` is handed to the library when it is not (by identity) the matrix the context
-already holds — SigmaU is one constant matrix per data set (src/utils.jl:17-33) — and re-used otherwise."""
+already holds — SigmaU is one constant matrix per data set (src/utils.jl:17-33) — and re-used otherwise.
+Cache contract: IDENTITY (`===`), not contents.  Pass the SAME `SigmaU` array on every score and the scalar `uNoise` as
+`covscale` (the replacement line does: `hip_mv_normal(SigmaU, uNoise)`); a temporary such as `SigmaU * uNoise` is a new
+array each time and is uploaded and validated again on every score, and a matrix changed in place is NOT noticed —
+hand over a copy (or set `c.cov = nothing`) after mutating one."""
 function mvn_score(c::Ctx, cov::Matrix{Float64}, covscale::Float64, x::Vector{Float64})
     if c.cov !== cov
         mvn_logpdf(c, cov, nothing, nothing)          # S = 0: hand over + validate (PosDefException if not PD)
@@ -483,34 +515,76 @@ _dot(doT) = throw(ArgumentError("vector interventions: fill(doT, n) of a vector 
 # finalizer on the vector frees the device context — hundreds of MB of HBM workspace — as soon as the object is
 # collected.  The finalizer touches no Dict (finalizers run at arbitrary allocation points); dead entries (a few words
 # each) are swept on the next lookup.  release!(g) does the same eagerly.
+# Two GPSLCObjects may share one posteriorSamples vector and differ in data or hyper-parameters (the pack depends on
+# nBurnIn:stepSize:nOuter, the context holds X, T, Y): the entry also records the identities of g.hyperparams, g.X, g.T, g.Y and is
+# rebuilt when any of them differs.  The cache contract is IDENTITY: an in-place change to g.X / g.T / g.Y or to the posterior
+# samples after the first prediction is not seen — call release!(g) after mutating.
 mutable struct _DeviceSide
     key::WeakRef
+    ids::NTuple{4,UInt}            # objectid of g.hyperparams, g.X, g.T, g.Y at the time the entry was built
     ctx::GPSLCHip.Ctx
     pack::Union{GPSLCHip.Pack,Nothing}
+    multi::Dict{Vector{Int},Vector{GPSLCHip.Ctx}}      # devices => one context per entry, each holding the data (ctxs(g, devices))
 end
 const _GPSLC_DEVICE = Dict{UInt,_DeviceSide}()
+_ids(g::GPSLCObject) = (objectid(g.hyperparams), objectid(g.X), objectid(g.T), objectid(g.Y))
+function _drop!(d::_DeviceSide)
+    GPSLCHip.destroy!(d.ctx)
+    foreach(cs -> foreach(GPSLCHip.destroy!, cs), values(d.multi))
+    empty!(d.multi)
+    d.pack = nothing                                   # n x nU x S doubles on the host
+    nothing
+end
 
 function _device_side(g::GPSLCObject)
     ps = g.posteriorSamples
+    for (k, v) in collect(_GPSLC_DEVICE)              # sweep: entries whose vector is gone release their pack and contexts
+        v.key.value === nothing && (_drop!(v); delete!(_GPSLC_DEVICE, k))
+    end
     filter!(kv -> kv.second.key.value !== nothing, _GPSLC_DEVICE)
     d = get(_GPSLC_DEVICE, objectid(ps), nothing)
-    if d === nothing || d.key.value !== ps || d.ctx.h == C_NULL
+    if d === nothing || d.key.value !== ps || d.ids != _ids(g) || d.ctx.h == C_NULL
+        d === nothing || _drop!(d)
         nX = g.X === nothing ? 0 : getNX(g)
         nU = getNU(g) === nothing ? 0 : getNU(g)
         c = GPSLCHip.Ctx(getN(g), nX, nU)
         GPSLCHip.set_data!(c, g.X, g.T, g.Y)           # Bool treatments become 0.0 / 1.0 here
-        d = _DeviceSide(WeakRef(ps), c, nothing)
+        d = _DeviceSide(WeakRef(ps), _ids(g), c, nothing, Dict{Vector{Int},Vector{GPSLCHip.Ctx}}())
         _GPSLC_DEVICE[objectid(ps)] = d
         finalizer(_ -> GPSLCHip.destroy!(c), ps)
     end
     d
 end
 
-"""release!(g): free g's device context and cached posterior pack now (otherwise: when g is garbage-collected)."""
+"""release!(g): free g's device contexts and cached posterior pack now (otherwise: when g is garbage-collected)."""
 function release!(g::GPSLCObject)
     d = pop!(_GPSLC_DEVICE, objectid(g.posteriorSamples), nothing)
-    d === nothing || GPSLCHip.destroy!(d.ctx)
+    d === nothing || (GPSLCHip.destroy!(d.ctx); _drop!(d))
     nothing
+end
+
+"""ctxs(g, devices): one context per entry of `devices` (GPU indices of this node, e.g. 0:7), each holding g.X, g.T, g.Y — what
+`GPSLCHip.predict_multi` shards the posterior samples over (SURVEY.md §8e; the loop src/prediction.jl:30-33).  Created on first use
+for that device list, freed with g."""
+function ctxs(g::GPSLCObject, devices)
+    d = _device_side(g)
+    key = Int[dev for dev in devices]
+    isempty(key) && throw(ArgumentError("devices must name at least one GPU"))
+    get!(d.multi, key) do
+        map(key) do dev
+            c = GPSLCHip.Ctx(d.ctx.n, d.ctx.nX, d.ctx.nU; device=dev)
+            GPSLCHip.set_data!(c, g.X, g.T, g.Y)
+            c
+        end
+    end
+end
+
+# One GPU (devices === nothing: the object's context on device 0) or the sharded call: same tuple (mS, vS, mI, ite).
+function _predict(g::GPSLCObject, devices, doT::Vector{Float64}; kw...)
+    pn = g.hyperparams.predictionCovarianceNoise
+    devices === nothing && return GPSLCHip.predict(ctx(g), posterior_pack(g), doT, pn; kw...)
+    mS, vS, mI, ite, _ = GPSLCHip.predict_multi(ctxs(g, devices), posterior_pack(g), doT, pn; kw...)
+    mS, vS, mI, ite
 end
 
 """ctx(g): the device context holding g.X, g.T, g.Y (src/types.jl:249-258), created on first use."""
@@ -535,9 +609,9 @@ end
 # ---- src/kernel.jl ------------------------------------------------------------------------------------------------
 function rbfKernelLogScalar(Xi::SupportedRBFVector, Xiprime::SupportedRBFVector, LS::SupportedRBFLengthscale)   # :13-19
     @assert (size(LS, 1) == size(Xi, 1) || size(LS) == ()) "vector lengthscale doesn't match individual"
-    x1 = reshape(GPSLCHip.f64(collect(Xi)), 1, :)
-    x2 = reshape(GPSLCHip.f64(collect(Xiprime)), 1, :)
-    GPSLCHip.rbf_log(GPSLCHip.kctx(), x1, x2, _ls(LS))[1, 1]
+    # five flops for one pair of individuals: stays on the host, in the reference's own arithmetic (src/kernel.jl:17) — a context
+    # lookup, two uploads, a launch and a download would cost 10^4 times the sum; the matrix methods below are the GPU's
+    return -sum((Xi .- Xiprime) .^ 2 ./ LS .^ 2)
 end
 
 function rbfKernelLog(X1::SupportedRBFMatrix, X2::SupportedRBFMatrix, LS::SupportedRBFLengthscale)              # :24-32
@@ -567,7 +641,9 @@ function _likelihood_blocks(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y, doT)
     c = GPSLCHip.dctx(n, X === nothing ? 0 : size(X, 2), _ncols(Um))
     GPSLCHip.set_data!(c, X, T, Y)
     b = GPSLCHip.likelihood_distribution(c, Um, uyLS, xyLS, tyLS, yScale, yNoise, _dot(doT))
-    Y, b[1], b[2], b[3], b[4], b[5], b[6], b[7]        # Y, CovWW, CovWWs, CovWWp, CovC11, CovC12, CovC21, CovC22 (:51)
+    # CovWW and CovWWp come back as the reference returns them, wrapped in Symmetric (src/likelihood.jl:31-32): a caller's
+    # `CovWWp \ y` then dispatches to Bunch-Kaufman as it does there, not to LU
+    Y, LinearAlgebra.Symmetric(b[1]), b[2], LinearAlgebra.Symmetric(b[3]), b[4], b[5], b[6], b[7]   # Y, CovWW, CovWWs, CovWWp, CovC11, CovC12, CovC21, CovC22 (:51)
 end
 
 function likelihoodDistribution(uyLS::Vector{Float64}, xyLS::Array{Float64}, tyLS::Float64, yNoise::Float64, yScale::Float64,
@@ -626,8 +702,8 @@ function ITEDistributions(g::GPSLCObject, doT::Intervention)                    
     GPSLCHip.ite_distributions(ctx(g), posterior_pack(g), _dot(doT), g.hyperparams.predictionCovarianceNoise)
 end
 
-function SATEDistributions(g::GPSLCObject, doT::Intervention)                                                      # :127-140
-    mS, vS, _, _ = GPSLCHip.predict(ctx(g), posterior_pack(g), [_dot(doT)], g.hyperparams.predictionCovarianceNoise)
+function SATEDistributions(g::GPSLCObject, doT::Intervention; devices=nothing)                                    # :127-140
+    mS, vS, _, _ = _predict(g, devices, [_dot(doT)])
     mS[:, 1], vS[:, 1]          # O(N^2) per posterior sample: the N x N covariance is never formed
 end
 
@@ -645,17 +721,16 @@ function _normals(n, spp, S, L, seed)
 end
 
 function sampleITE(g::GPSLCObject, doT::Intervention; samplesPerPosterior::Int64=10,
-                   seed::Union{Nothing,Integer}=nothing)                                                           # :86-89
+                   seed::Union{Nothing,Integer}=nothing, devices=nothing)                                          # :86-89
     n, S = getN(g), getNumPosteriorSamples(g)
     sd, z = _normals(n, samplesPerPosterior, S, 1, seed)
-    _, _, _, ite = GPSLCHip.predict(ctx(g), posterior_pack(g), [_dot(doT)], g.hyperparams.predictionCovarianceNoise;
-                                    spp=samplesPerPosterior, seed=sd, z=z, want_draws=true)
+    _, _, _, ite = _predict(g, devices, [_dot(doT)]; spp=samplesPerPosterior, seed=sd, z=z, want_draws=true)
     ite[1, :, :]                                                          # n x (S * spp), sample outer / draw inner (:100-107)
 end
 
 function sampleSATE(g::GPSLCObject, doT::Intervention; samplesPerPosterior::Int64=10,
-                    seed::Union{Nothing,Integer}=nothing)                                                          # :108-111
-    MeanSATEs, VarSATEs = SATEDistributions(g, doT)
+                    seed::Union{Nothing,Integer}=nothing, devices=nothing)                                         # :108-111
+    MeanSATEs, VarSATEs = SATEDistributions(g, doT; devices=devices)
     seed === nothing || return GPSLCHip.sate_samples(MeanSATEs, VarSATEs, samplesPerPosterior; seed=UInt64(seed))
     z = randn(length(MeanSATEs) * samplesPerPosterior)
     GPSLCHip.sate_samples(MeanSATEs, VarSATEs, samplesPerPosterior; z=z)  # normal(mean, var): variance as sigma (:159)
@@ -674,17 +749,16 @@ end
 # ---- src/prediction.jl --------------------------------------------------------------------------------------------
 function predictCounterfactualEffects(g::GPSLCObject, nSamplesPerMixture::Int64; fidelity::Int64=100,
                                       minDoT=min(g.T...), maxDoT=max(g.T...),
-                                      seed::Union{Nothing,Integer}=nothing)                                        # :23-36
+                                      seed::Union{Nothing,Integer}=nothing, devices=nothing)                       # :23-36
     delta = abs(maxDoT - minDoT)
     step = delta / fidelity
     doTrange = minDoT:step:maxDoT                                          # :24-28
     L, n, S = length(doTrange), getN(g), getNumPosteriorSamples(g)
     sd, z = _normals(n, nSamplesPerMixture, S, L, seed)
     # one factorisation of A per posterior sample, shared by its L levels; `ite` comes back in the reference's
-    # layout (L x n x S*spp, level index fastest)
-    _, _, _, ite = GPSLCHip.predict(ctx(g), posterior_pack(g), Float64.(collect(doTrange)),
-                                    g.hyperparams.predictionCovarianceNoise; spp=nSamplesPerMixture, seed=sd, z=z,
-                                    want_draws=true)
+    # layout (L x n x S*spp, level index fastest).  devices = 0:7 shards the posterior samples — the loop of :30-33 — over the
+    # eight GPUs of a node: ONE ccall (gpslc_predict_multi), same tensor bit for bit
+    _, _, _, ite = _predict(g, devices, Float64.(collect(doTrange)); spp=nSamplesPerMixture, seed=sd, z=z, want_draws=true)
     return ite, doTrange
 end
 

@@ -5,7 +5,8 @@
  *       x' C^-1 x = x'x / noise - scale (sum x)^2 / (noise (noise + n scale))          (Sherman-Morrison)
  * through gpslc_gp_logpdf (S parameter sets), gpslc_nodes_logpdf (heterogeneous nodes) and, for n large enough to
  * leave the single-workgroup kernels, the tiled path; then the ensemble driver (gpslc_set_data, gpslc_predict,
- * gpslc_set_ensemble): the reference's exact-zero identities at n = 300 and the placement of a sample in an ensemble.
+ * gpslc_set_ensemble, gpslc_predict_multi): the reference's exact-zero identities at n = 300, the placement of a sample in an
+ * ensemble, and the ensemble sharded over two contexts.
  * Exit code 0 = all within 1e-10 relative (exact where stated). */
 #include <math.h>
 #include <stdio.h>
@@ -121,6 +122,27 @@ int main(void) {
             if (d1[e] != dr[(size_t)L * n * spp * 1 + e]) { printf("placed draws differ at element %zu\n", e); ++bad; break; }
         if (gpslc_set_ensemble(ctx, 5, 3) != -3 || gpslc_set_ensemble(ctx, 0, 0) != GPSLC_OK) { printf("gpslc_set_ensemble argument check\n"); ++bad; }
         printf("predict from C: MeanSATE(level 1) = %.12g %.12g %.12g\n", mS[S], mS[S + 1], mS[S + 2]);
+        /* (f) gpslc_predict_multi: the same ensemble sharded over two contexts (both on device 0 here; one per GPU on a node):
+         *     every output, the seeded draws included, equals the single-context call bit for bit. */
+        {
+            gpslc_ctx* c2 = NULL;
+            if (gpslc_create(&c2, 0, n, nX, nU, GPSLC_FLAG_DEFAULT) != GPSLC_OK || gpslc_set_data(c2, X, T, Y) != GPSLC_OK) { printf("second ctx failed\n"); return 7; }
+            gpslc_ctx* both[2] = {ctx, c2};
+            double mS2[6], vS2[6];
+            int32_t info[3] = {-1, -1, -1};
+            double* mI2 = (double*)malloc(sizeof(double) * n * S * L);
+            double* dr2 = (double*)malloc(sizeof(double) * L * n * S * spp);
+            st = gpslc_predict_multi(2, both, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, pn, spp, 5, NULL, mS2, vS2, mI2, dr2, info);
+            if (st != GPSLC_OK) { printf("gpslc_predict_multi: status %d (%s)\n", st, gpslc_last_error(ctx)); return 7; }
+            for (int e = 0; e < S * L; ++e) if (mS2[e] != mS[e] || vS2[e] != vS[e]) { printf("multi: SATE differs at %d\n", e); ++bad; break; }
+            for (size_t e = 0; e < (size_t)n * S * L; ++e) if (mI2[e] != mI[e]) { printf("multi: MeanITE differs at %zu\n", e); ++bad; break; }
+            for (size_t e = 0; e < (size_t)L * n * S * spp; ++e) if (dr2[e] != dr[e]) { printf("multi: draws differ at %zu\n", e); ++bad; break; }
+            if (info[0] | info[1] | info[2]) { printf("multi: info not zero\n"); ++bad; }
+            gpslc_ctx* twice[2] = {ctx, ctx};
+            if (gpslc_predict_multi(2, twice, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, pn, spp, 5, NULL, mS2, vS2, NULL, NULL, NULL) != -2) { printf("multi: a ctx listed twice must be refused\n"); ++bad; }
+            free(mI2); free(dr2);
+            gpslc_destroy(c2);
+        }
         free(X); free(T); free(Y); free(U); free(mI); free(dr); free(d1);
         gpslc_destroy(ctx);
     }

@@ -1,0 +1,117 @@
+"""gpslc_predict_multi (include/gpslc_hip.h): the sharded ensemble behind the C ABI — the partition of the loop
+src/prediction.jl:30-33 over src/estimation.jl:78-84 into contiguous blocks of posterior samples, one context and one host
+thread per block.  The pool hands out one-GPU boxes, so the contexts of these tests share device 0 (the header allows it);
+what they pin is the contract: every output, seeded draws included, equals ONE gpslc_predict call bit for bit, whatever the
+number of contexts.  Nothing here has run on two physical GPUs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert a.shape == b.shape
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("S,L", [(5, 1), (7, 3), (2, 2)])
+def test_multi_equals_the_single_context_call_bit_for_bit(gp, devices, S, L):
+    c = cases.make_case(150, "UX", False, S=S, seed=21)
+    g = cases.gpslc_object(gp, c)
+    doT = np.linspace(0.2, 0.8, L)
+    # seeded draws (the library's Philox stream placed per shard) and caller normals
+    one = gp.predict(g, doT, want_mean_ite=True, spp=3, seed=17, want_draws=True)
+    many = gp.predict(g, doT, want_mean_ite=True, spp=3, seed=17, want_draws=True, devices=devices)
+    for a, b in zip(one, many):
+        _same(a, b)
+    z = np.random.default_rng(3).standard_normal((150, 3, S, L))
+    one = gp.predict(g, doT, want_mean_ite=True, spp=3, z=z, want_draws=True)
+    many = gp.predict(g, doT, want_mean_ite=True, spp=3, z=z, want_draws=True, devices=devices)
+    for a, b in zip(one, many):
+        _same(a, b)
+    # SATE only (no large output requested)
+    ms1, vs1, _ = gp.predict(g, doT)
+    msm, vsm, _ = gp.predict(g, doT, devices=devices)
+    _same(ms1, msm)
+    _same(vs1, vsm)
+
+
+def test_multi_multi_tile_matrix_and_more_contexts_than_samples(gp):
+    """n = 300 (three tiles per side), 4 contexts for 3 samples: one shard is empty."""
+    c = cases.make_case(300, "UX", True, S=3, seed=5)
+    g = cases.gpslc_object(gp, c)
+    one = gp.predict(g, [0.0, 1.0], want_mean_ite=True, spp=2, seed=4, want_draws=True)
+    many = gp.predict(g, [0.0, 1.0], want_mean_ite=True, spp=2, seed=4, want_draws=True, devices=[0, 0, 0, 0])
+    for a, b in zip(one, many):
+        _same(a, b)
+
+
+def test_predict_counterfactual_effects_over_devices(gp):
+    c = cases.make_case(150, "U", False, S=4, seed=8)
+    g = cases.gpslc_object(gp, c)
+    a, ra = gp.predictCounterfactualEffects(g, 2, fidelity=5, seed=9)
+    b, rb = gp.predictCounterfactualEffects(g, 2, fidelity=5, seed=9, devices=[0, 0])
+    _same(ra, rb)
+    _same(a, b)
+
+
+def test_multi_info_and_argument_errors(gp):
+    c = cases.make_case(24, "UX", False, S=4, seed=2)
+    g = cases.gpslc_object(gp, c)
+    cs = g.ctxs([0, 0])
+    lib = cs[0].lib
+    S, n = 4, 24
+    doT = np.array([0.5])
+    ms, vs = np.empty(S), np.empty(S)
+    info = np.full(S, -7, dtype=np.int32)
+
+    def call(nctx, hs, S_=S, info_=info):
+        return lib.gpslc_predict_multi(nctx, hs, S_, *g._params(), 1, C.c_void_p(doT.ctypes.data), 1e-10, 0, 0, None,
+                                       C.c_void_p(ms.ctypes.data), C.c_void_p(vs.ctypes.data), None, None,
+                                       None if info_ is None else info_.ctypes.data_as(C.POINTER(C.c_int32)))
+
+    hs = (C.c_void_p * 2)(cs[0].h, cs[1].h)
+    assert call(2, hs) == 0
+    assert not info.any()
+    ref = gp.predict(g, doT)
+    assert np.array_equal(ms, ref[0][:, 0]) and np.array_equal(vs, ref[1][:, 0])
+    assert call(0, hs) == -1                                   # nctx < 1
+    assert call(2, None) == -2                                 # ctxs NULL
+    dup = (C.c_void_p * 2)(cs[0].h, cs[0].h)
+    assert call(2, dup) == -2                                  # the same ctx twice
+    assert b"twice" in lib.gpslc_last_error(cs[0].h)
+    assert call(2, hs, S_=-1) == -3                            # S is argument #3 of this signature
+    other = gp.Context(25, g.getNX(), g.getNU())
+    mixed = (C.c_void_p * 2)(cs[0].h, other.h)
+    assert call(2, mixed) == -2                                # contexts of different shapes
+    other.close()
+    assert call(2, hs, S_=0) == 0
+
+
+def test_ensemble_placement_is_checked_and_cleared(gp):
+    """a placement that leaves no room for the call's samples is an argument error (it used to make the stream ids
+    of the last samples collide with the next level's), and gpslc_set_data drops a stale placement."""
+    c = cases.make_case(24, "UX", False, S=4, seed=2)
+    g = cases.gpslc_object(gp, c)
+    ctx = g.ctx()
+    lib = ctx.lib
+    assert lib.gpslc_set_ensemble(ctx.h, 2, 5) == 0          # room for 3 samples from offset 2
+    with pytest.raises(gp.GPSLCError) as e:
+        gp.predict(g, [0.5], spp=1, seed=1, want_draws=True)   # S = 4 > 3
+    assert e.value.status == -2 and "S_total" in str(e.value)
+    ctx.set_data(g.X, g.T, g.Y)                               # a new data set: placement cleared
+    gp.predict(g, [0.5], spp=1, seed=1, want_draws=True)
+    # a placement on ctxs[0] is the placement of the whole multi call
+    full = gp.predict(g, [0.5], spp=2, seed=3, want_draws=True)[3]
+    g2 = cases.gpslc_object(gp, cases.make_case(24, "UX", False, S=4, seed=2))
+    sub = gp.GPSLCObject(g2.X, g2.T, g2.Y, g2.U[:, :, 1:], g2.uyLS[:, 1:], g2.xyLS[:, 1:], g2.tyLS[1:], g2.yNoise[1:],
+                         g2.yScale[1:])
+    cs = sub.ctxs([0, 0])
+    assert lib.gpslc_set_ensemble(cs[0].h, 1, 4) == 0          # samples 1..3 of an ensemble of 4
+    part = gp.predict(sub, [0.5], spp=2, seed=3, want_draws=True, devices=[0, 0])[3]
+    assert np.array_equal(part, full[:, :, 2:])

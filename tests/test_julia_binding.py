@@ -20,7 +20,7 @@ C_TYPES = {
     "int64_t*": "pi64", "char*": "cstr", "gpslc_node*": "pnode", "gpslc_pack_header*": "phdr", "void": "void",
 }
 JL_TYPES = {
-    "Ref{Ptr{Cvoid}}": "ctxpp", "Ptr{Cvoid}": "ctx", "Cint": "int", "Int64": "i64", "Int32": "i32", "UInt32": "u32",
+    "Ref{Ptr{Cvoid}}": "ctxpp", "Ptr{Ptr{Cvoid}}": "ctxpp", "Ptr{Cvoid}": "ctx", "Cint": "int", "Int64": "i64", "Int32": "i32", "UInt32": "u32",
     "UInt64": "u64", "Float64": "f64", "Ptr{Float64}": "pf64", "Ref{Float64}": "pf64", "Ptr{Int32}": "pi32",
     "Ref{Int64}": "pi64", "Ptr{Int64}": "pi64", "Cstring": "cstr", "Ptr{GPSLCNode}": "pnode",
     "Ref{GPSLCNode}": "pnode", "Ref{PackHeader}": "phdr", "Ptr{PackHeader}": "phdr",
@@ -420,3 +420,74 @@ def test_shim_methods_have_the_reference_signatures():
             match = [kws for pos, kws in mine if types(pos) == types(sig["positional"])]
             assert len(match) == 1, f"{name}{sig['positional']} ({sig['file']}) has no method with the same positional types in the shim"
             assert set(sig["keywords"]) <= set(match[0]), (name, sig["keywords"], match[0])
+
+
+# ---- round 5: VERDICT r04 "next" items 2 and 6, ADVICE r04 (Julia shim residuals) ---------------------------------------
+def _blocks_by_first_line(src):
+    return dict((sig.splitlines()[0], (sig, body)) for sig, body in _function_blocks(src))
+
+
+def test_likelihood_distribution_returns_symmetric_wrappers_where_the_reference_does():
+    """src/likelihood.jl:31-32, 51: CovWW and CovWWp are `Symmetric` in the tuple the reference returns (positions 2 and 4)."""
+    sig, body = _blocks_by_first_line(_part2())["function _likelihood_blocks(uyLS, xyLS, tyLS, yNoise, yScale, U, X, T, Y, doT)"]
+    ret = [l for l in _strip(body).splitlines() if l.strip().startswith("Y, ")]
+    assert len(ret) == 1
+    parts = _split_top(ret[0].strip())
+    assert len(parts) == 8
+    assert parts[1] == "LinearAlgebra.Symmetric(b[1])" and parts[3] == "LinearAlgebra.Symmetric(b[3])"
+    assert [p for i, p in enumerate(parts) if i not in (1, 3)] == ["Y", "b[2]", "b[4]", "b[5]", "b[6]", "b[7]"]
+    assert "import LinearAlgebra" in _part2()
+
+
+def test_scalar_kernel_stays_on_the_host():
+    """rbfKernelLogScalar is five flops (src/kernel.jl:17): no ccall, no context, no upload may be reachable from it."""
+    blocks = _blocks_by_first_line(_part2())
+    key = [k for k in blocks if k.startswith("function rbfKernelLogScalar(")]
+    assert len(key) == 1
+    body = _strip(blocks[key[0]][1])
+    assert "GPSLCHip." not in body and "ccall" not in body and "kctx" not in body
+    assert "-sum((Xi .- Xiprime) .^ 2 ./ LS .^ 2)" in body
+
+
+def test_dctx_evicts_one_least_recently_used_context():
+    src = julia_source()
+    module = src[src.index("module GPSLCHip"):src.index("end # module GPSLCHip")]
+    body = dict((sig.splitlines()[0], b) for sig, b in _function_blocks(module))["function dctx(n::Integer, nX::Integer, nU::Integer)"]
+    assert "empty!(DCTX)" not in body and "foreach(destroy!" not in body        # round 4 destroyed all eight at once
+    assert "argmin(DCTX_USED)" in body and "delete!(DCTX, lru)" in body and "DCTX_USED[key] =" in body
+    assert "destroy!" not in body                                               # a caller may still hold the evicted context
+
+
+def test_ensemble_entry_points_reach_several_gpus_with_one_ccall():
+    """VERDICT r04 missing #1: predictCounterfactualEffects / sampleITE / sampleSATE / SATEDistributions take `devices` and go
+    through ONE gpslc_predict_multi call; the contexts per device hold the data and are freed with the object."""
+    src = _part2()
+    blocks = _blocks_by_first_line(src)
+    for start in ("function predictCounterfactualEffects(g::GPSLCObject", "function sampleITE(g::GPSLCObject",
+                  "function sampleSATE(g::GPSLCObject", "function SATEDistributions(g::GPSLCObject"):
+        key = [k for k in blocks if k.startswith(start)]
+        assert len(key) == 1, start
+        sig, body = blocks[key[0]]
+        assert "devices=nothing" in sig, sig
+        assert "_predict(g, devices," in body or "devices=devices" in body, start
+        assert "GPSLCHip.predict(" not in body, start
+    sig, body = blocks["function _predict(g::GPSLCObject, devices, doT::Vector{Float64}; kw...)"]
+    assert "GPSLCHip.predict_multi(ctxs(g, devices), posterior_pack(g), doT, pn; kw...)" in body
+    assert "devices === nothing && return GPSLCHip.predict(ctx(g), posterior_pack(g), doT, pn; kw...)" in body
+    sig, body = blocks["function ctxs(g::GPSLCObject, devices)"]
+    assert "GPSLCHip.Ctx(d.ctx.n, d.ctx.nX, d.ctx.nU; device=dev)" in body and "GPSLCHip.set_data!(c, g.X, g.T, g.Y)" in body
+    module = julia_source()
+    assert module.count("ccall((:gpslc_predict_multi, lib)") == 1
+    assert "ctxs = Ptr{Cvoid}[c.h for c in cs]" in module and "GC.@preserve cs ctxs" in module
+
+
+def test_device_side_key_covers_data_and_hyperparameters():
+    """two GPSLCObjects sharing one posteriorSamples vector but differing in data or hyper-parameters must not get
+    each other's context / pack; dead entries drop their pack."""
+    src = _part2()
+    blocks = _blocks_by_first_line(src)
+    assert "_ids(g::GPSLCObject) = (objectid(g.hyperparams), objectid(g.X), objectid(g.T), objectid(g.Y))" in src
+    body = blocks["function _device_side(g::GPSLCObject)"][1]
+    assert "d.ids != _ids(g)" in body and "_drop!(v)" in body
+    drop = blocks["function _drop!(d::_DeviceSide)"][1]
+    assert "d.pack = nothing" in drop and "GPSLCHip.destroy!(d.ctx)" in drop
