@@ -45,14 +45,14 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBPS = 8000.0
-# pure fp64 VALU issue time per posterior sample at N=4096 D=8 nU=2, 2.4 GHz: SQ_ACTIVE_INST_VALU x 4 clocks / 1024 SIMDs per
-# 1,024-sample launch (profiles/r04_pmc_gram.md, r04_pmc_ite_mean.md — unchanged since round 3; round 2: 18.6 and 31.4 — table-driven exp, and the
-# MeanITE pass lost one of its two exp per pair)
-C2_HBM_BYTES_PER_SAMPLE = 38.6e6      # profiles/r04_pmc_n1024_per_kernel.md (re-measured when the schedule changes)
-GRAM_VALU_US_N4096 = 17.4
-ITE_MEAN_VALU_US_N4096 = 19.1
-KERNEL_SRC = os.path.join(ROOT, "causalgpslc.jl_amd", "csrc", "k_tilegemm.hip")
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_tile_gemm.json")
+# Three figures (HBM bytes per posterior sample at config 2; Gram / MeanITE fp64-VALU issue time per sample) are MEASURED
+# quantities: they live in profiles/r05_bench_constants.json, each stamped with the git blob hashes of the sources it was measured
+# on (tools/collect_profiles.py), and are withheld — like roofline.traffic — when any of those sources has changed since.
+CSRC = os.path.join(ROOT, "causalgpslc.jl_amd", "csrc")
+KERNEL_SRC = os.path.join(CSRC, "k_tilegemm.hip")
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_pmc_tile_gemm.json") for r in ("r05", "r04"))
+                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r05_pmc_tile_gemm.json"))
+BENCH_CONSTANTS = os.path.join(ROOT, "profiles", "r05_bench_constants.json")
 
 
 def parse():
@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--unit-b-levels", type=int, default=16, help="intervention levels per posterior sample (they share one factor of A)")
     ap.add_argument("--unit-b-spp", type=int, default=10, help="draws per (sample, level): the reference's default")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="timed regions of --steps steps each: `value` is the first, `value_runs` lists all (box-to-box spread is "
+                         "about 1 %; this shows the run-to-run spread on one box)")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[3] leg (64 intervention levels per sample)")
     ap.add_argument("--config4-levels", type=int, default=64)
     ap.add_argument("--config4-steps", type=int, default=2)
@@ -109,6 +112,22 @@ def pmc_traffic(default_config):
         return None, f"STALE: k_tilegemm.hip changed since {os.path.relpath(PMC_SUMMARY, ROOT)} was taken; withheld"
     return pm.get("hbm_bytes_per_launch"), ("bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), "
                                              f"{os.path.relpath(PMC_SUMMARY, ROOT)}; kernel source hash matches")
+
+
+def measured_constant(name):
+    """(value, note) of a measured constant of profiles/r05_bench_constants.json, or (None, reason) when the file is missing or
+    one of the sources the measurement was taken on has changed (git blob hash) — a remembered number must not describe a
+    kernel it was not measured on."""
+    if not os.path.exists(BENCH_CONSTANTS):
+        return None, f"{os.path.relpath(BENCH_CONSTANTS, ROOT)} is missing"
+    rec = json.load(open(BENCH_CONSTANTS)).get(name)
+    if not rec:
+        return None, f"{name} is not in {os.path.relpath(BENCH_CONSTANTS, ROOT)}"
+    for rel, sha in rec.get("source_shas", {}).items():
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path) or git_blob_sha(path) != sha:
+            return None, f"STALE: {rel} changed since {rec.get('from', 'the measurement')} was taken; withheld"
+    return rec["value"], f"{rec.get('from', '')}; source hashes match ({', '.join(sorted(rec.get('source_shas', {})))})"
 
 
 def count_gpus_sysfs():
@@ -338,7 +357,7 @@ def measure_units(gp, synth, np, torch, a, dev, local_rank, X, T, Y, obj, dX, dT
     return out
 
 
-def run_config(gp, synth, np, torch, dev, local_rank, n, D, K, S, L, binary_t, fp32, steps, warmup, label):
+def run_config(gp, synth, np, torch, dev, local_rank, n, D, K, S, L, binary_t, fp32, steps, warmup, label, literal_golden=None):
     """One short timed run of unit A (with MeanITE) on another BASELINE configuration, inputs resident in HBM; this
     run's first unit is checked against the structured oracle evaluated in fp64 (SURVEY §8d tolerances)."""
     X, T, Y, obj = synth.make_dataset(n, D, binary_t=binary_t)
@@ -380,15 +399,19 @@ def run_config(gp, synth, np, torch, dev, local_rank, n, D, K, S, L, binary_t, f
            "ms_per_step": 1e3 * dt / steps, "dtype": "f64 factorisation, f32 kernel build" if fp32 else "f64",
            "algorithmic_flop_per_unit": flop, "ceiling_units_per_s": FP64_PEAK_TFLOPS * 1e12 / flop,
            "frac_of_ceiling": val * flop / (FP64_PEAK_TFLOPS * 1e12)}
-    if (n, D, K, L) == (1024, 4, 1, 1) and not fp32:
-        # Config 2 is bandwidth-bound, not MFMA-bound (profiles/r04_ab_experiments.md §5, r04_pmc_n1024_per_kernel.md): the
-        # left-looking schedule moves ~41 MB of HBM traffic per posterior sample (PMC: FETCH_SIZE x 2 + WRITE_SIZE summed over
-        # the kernels of a 4,096-sample chunk), nine times the 4.7 MB matrix.  Round-4 measurement of the round-4 kernels.
-        rec["hbm"] = {"bytes_per_unit": C2_HBM_BYTES_PER_SAMPLE, "achieved": val * C2_HBM_BYTES_PER_SAMPLE / 1e9,
-                      "peak": HBM_PEAK_GBPS, "roofline_unit": "GB/s", "frac": val * C2_HBM_BYTES_PER_SAMPLE / 1e9 / HBM_PEAK_GBPS,
-                      "ceiling_units_per_s": HBM_PEAK_GBPS * 1e9 / C2_HBM_BYTES_PER_SAMPLE,
-                      "note": "the binding roof of this configuration: HBM bytes per sample from the PMC passes of "
-                              "profiles/r04_pmc_n1024_per_kernel.md x samples/s; frac_of_ceiling above is against the MFMA peak"}
+    if (n, D, K, L, S) == (1024, 4, 1, 1, 8192) and not fp32:
+        # Config 2 moves ~39 MB of HBM traffic per posterior sample (PMC: FETCH_SIZE x 2 + WRITE_SIZE summed over the kernels of
+        # an 8,192-sample chunk), eight times the 4.7 MB matrix: the left-looking schedule's bytes (profiles/r04_ab_experiments.md
+        # §5).  The figure is read from the committed measurement of THIS chunk size and THESE sources, or withheld.
+        bps, bnote = measured_constant("c2_hbm_bytes_per_sample")
+        if bps is None:
+            rec["hbm"] = {"bytes_per_unit": None, "frac": None, "note": bnote}
+        else:
+            rec["hbm"] = {"bytes_per_unit": bps, "achieved": val * bps / 1e9,
+                          "peak": HBM_PEAK_GBPS, "roofline_unit": "GB/s", "frac": val * bps / 1e9 / HBM_PEAK_GBPS,
+                          "ceiling_units_per_s": HBM_PEAK_GBPS * 1e9 / bps,
+                          "note": "HBM bytes per sample from the PMC passes (" + bnote + ") x samples/s; frac_of_ceiling above "
+                                  "is against the MFMA peak"}
     names = ("trailing_update_kernel", "fused_in_panel_kernel")
     for nm, (ln, ms, fl) in zip(names, prof):
         if ln > 0 and ms > 0:
@@ -408,7 +431,60 @@ def run_config(gp, synth, np, torch, dev, local_rank, n, D, K, S, L, binary_t, f
                      "ok": bool(abs(gm - rm) <= tol * abs(rm) + 1e-12 and
                                 abs(gv - rv) <= tol * abs(rv) + 1e-9 * float(post["yScale"][0])),
                      "reference": "structured CPU restatement in fp64 (oracle.structured_sate), first unit of this run"}
+    if literal_golden:
+        lit = literal_golden_check(gp, np, torch, dev, local_rank, n, D, K, X, T, Y, obj, binary_t, fp32, literal_golden)
+        rec["parity"]["literal_golden"] = lit
+        rec["parity"]["ok"] = bool(rec["parity"]["ok"] and lit.get("ok", True))
     return rec
+
+
+def literal_golden_check(gp, np, torch, dev, local_rank, n, D, K, X, T, Y, obj, binary_t, fp32, path):
+    """The committed LITERAL restatement of this configuration's shape (tests/golden/config5_literal.npz: one (sample, level) unit
+    at N = 16384, 11 minutes of host CPU — tests/golden/make_golden_config5.py) against one more gpslc_predict_dev call on the
+    golden's own inputs, in the mode this configuration is timed in.  The inputs are regenerated from the same seeds and their
+    checksums compared with the ones stored beside the outputs; on a mismatch nothing is claimed."""
+    from causalgpslc_jl_amd import synth
+    gold = np.load(path)
+    gn, gD, gK, gS = (int(v) for v in gold["shape"])
+    if (gn, gD, gK) != (n, D, K) or gS != 1:
+        return {"skipped": f"the golden holds N={gn} D={gD} nU={gK}"}
+    post = synth.make_posterior(n, D, K, 1, obj)
+    chk = np.array([X.sum(), T.sum(), Y.sum(), post["U"].sum(), post["uyLS"].sum(), post["xyLS"].sum(),
+                    post["tyLS"][0], post["yNoise"][0], post["yScale"][0]])
+    if not np.allclose(chk, gold["in_checksums"], rtol=1e-13, atol=0):
+        return {"skipped": "the synthetic generator no longer reproduces the golden's inputs (checksums differ)"}
+
+    def to_dev(x):
+        return torch.from_numpy(np.ascontiguousarray(x.reshape(-1, order="F"))).to(dev)
+
+    def ptr(t):
+        return C.c_void_p(t.data_ptr())
+
+    ctx = gp.Context(n, D, K, device=local_rank, fp32_kernel=fp32)
+    dX, dT, dY = to_dev(X), to_dev(T), to_dev(Y)
+    ctx.check(ctx.lib.gpslc_set_data_dev(ctx.h, ptr(dX), ptr(dT), ptr(dY)))
+    packs = [to_dev(post[k]) for k in ("U", "uyLS", "xyLS", "tyLS", "yScale", "yNoise")]
+    ddo = to_dev(np.array([float(gold["doT"])]))
+    mS = torch.empty(1, dtype=torch.float64, device=dev)
+    vS = torch.empty(1, dtype=torch.float64, device=dev)
+    mI = torch.empty(n, dtype=torch.float64, device=dev)
+    ctx.check(ctx.lib.gpslc_predict_dev(ctx.h, 1, *[ptr(t) for t in packs], 1, ptr(ddo), 1e-10, 0, 0, None,
+                                        ptr(mS), ptr(vS), ptr(mI), None))
+    torch.cuda.synchronize()
+    ctx.close()
+    rm, rv, m_ref = float(gold["meanSATE"]), float(gold["varSATE"]), gold["meanITE"]
+    gm, gv, mi = float(mS.item()), float(vS.item()), mI.cpu().numpy()
+    tol = 1e-6
+    em, ev = abs(gm - rm) / abs(rm), abs(gv - rv) / abs(rv)
+    ei = float(np.max(np.abs(mi - m_ref)) / np.max(np.abs(m_ref)))
+    return {"mean_rel_err": em, "var_rel_err": ev, "mean_ite_rel_err": ei, "tolerance": tol,
+            "mode": "fp32 kernel build + fp64 Cholesky" if fp32 else "fp64",
+            "ok": bool(abs(gm - rm) <= tol * abs(rm) + 1e-12 and abs(gv - rv) <= tol * abs(rv) + 1e-9 * float(post["yScale"][0])
+                       and ei <= tol),
+            "reference": "LITERAL CPU restatement at full size (oracle.ite_distributions + conditional_sate: 5 kernel builds, 3 "
+                         "symmetric-indefinite solves, 4 GEMMs; src/likelihood.jl:24-49, src/estimation.jl:46-47, 82, 116-121), "
+                         f"committed as {os.path.relpath(path, ROOT)} ({float(gold['seconds']):.0f} s of host CPU when it was "
+                         "generated); unit = (S = 1 posterior of seed 1234, doT = 1) on this configuration's data set"}
 
 
 def write_bench_pack(path, X, T, Y, post, binary_t):
@@ -563,6 +639,21 @@ def main():
         dt = float(tt.item())
     launches, kms, kflop = ctx.profile_get(0)      # tile_gemm_nt_kernel<1, 0>: the dominant kernel
     launches1, kms1, kflop1 = ctx.profile_get(1)   # tile_fused_strip_kernel: in-panel column update fused with the panel solve
+    # the spread of the measurement: the same K steps timed again (--repeats - 1 more regions, bracketed like the first).  `value`
+    # stays the FIRST region (exactly K steps after W warm-up steps, as the contract says); value_runs lists all of them.
+    region_s = [dt]
+    for _ in range(max(0, a.repeats - 1)):
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        d1 = time.perf_counter() - t1
+        if use_dist:
+            tt = torch.tensor([d1], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d1 = float(tt.item())
+        region_s.append(d1)
     kname = "tile_gemm_nt_kernel<1, 0> (f64 MFMA tile update: trailing updates of the blocked Cholesky)"
     kname1 = "tile_fused_strip_kernel<8> (f64 MFMA tile update: in-panel column update fused with the panel solve)"
 
@@ -633,6 +724,27 @@ def main():
                     e = max(e, float(np.max(np.abs(mi4[:, l] - m_ref)) / np.max(np.abs(m_ref))))
                 par["mean_ite_rel_err"] = e
                 okm = okm and e <= tol
+            if not a.no_cpu_baseline:
+                # one (sample, level) unit of this region against the LITERAL restatement as well (5 kernel builds, 3 symmetric-
+                # indefinite solves, 4 GEMMs: src/likelihood.jl:24-49, src/estimation.jl:46-47, 82, 116-121) — the structured
+                # restatement above shares the GPU path's algebra, this one does not
+                ll = L4 // 2
+                tl0 = time.perf_counter()
+                Ml, Cl = orc.ite_distributions([p0], X, T, Y, float(doT4[ll]))
+                lm, lv = orc.conditional_sate(Ml[0], Cl[0])
+                lit = {"level": ll, "doT": float(doT4[ll]), "mean_rel_err": abs(float(gm4[ll]) - lm) / abs(lm),
+                       "var_rel_err": abs(float(gv4[ll]) - lv) / abs(lv), "seconds": time.perf_counter() - tl0,
+                       "reference": "literal CPU restatement (oracle.ite_distributions + conditional_sate), fp64"}
+                okl = (abs(float(gm4[ll]) - lm) <= tol * abs(lm) + 1e-12 and
+                       abs(float(gv4[ll]) - lv) <= tol * abs(lv) + 1e-9 * float(post["yScale"][0]))
+                if mI4 is not None:
+                    mil = mI4.cpu().numpy().reshape(n, Sr, L4, order="F")[:, 0, ll]
+                    lit["mean_ite_rel_err"] = float(np.max(np.abs(mil - Ml[0])) / np.max(np.abs(Ml[0])))
+                    okl = okl and lit["mean_ite_rel_err"] <= tol
+                lit["ok"] = bool(okl)
+                par["literal_unit"] = lit
+                okm = okm and okl
+                del Ml, Cl
             par["ok"] = okm and okv
             c4["parity"] = par
         del mS4, vS4, mI4
@@ -658,6 +770,7 @@ def main():
             "metric": "posterior samples/sec (kernel+chol+predict) at N=%d; SATE rel-err vs CPU" % n,
             "value": val, "unit": "posterior samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value_runs": [total_samples / d for d in region_s],
             "dtype": "f64" if not a.fp32_kernel else "f64 factorisation, f32 kernel build",
             "data": "synthetic" + (" (MEASUREMENT BUILD libgpslc_hip_diag.so — not a result)" if a.diag_lib else "") + (f" (MEASUREMENT BUILD {os.path.basename(a.lib)} — not a result)" if a.lib else "") + (" (TIMING ONLY: results unchecked)" if a.timing_only else "") + (" (REHEARSAL: all ranks on one GPU, gloo — not a result)" if rehearsal else ""),
             "config": {"workload": f"Synthetic N={n} D={D} nU={K}, unit A (Gram build + potrf + alpha + MeanITE + "
@@ -728,12 +841,17 @@ def main():
             if (n, D, K, L) == (4096, 8, 2, 1) and not a.no_mean_ite and not a.fp32_kernel:
                 # fp64 VALU and fp64 MFMA share one datapath on gfx950 (profiles/r02_coexec_f64_microbench.txt): the
                 # irreducible fp64 VALU issue time of the Gram build and the MeanITE pass adds to the MFMA time
-                valu_s = GRAM_VALU_US_N4096 * 1e-6 + ITE_MEAN_VALU_US_N4096 * 1e-6
-                ua["ceiling_shared_datapath_units_per_s"] = 1.0 / (flop_a / (FP64_PEAK_TFLOPS * 1e12) + valu_s)
-                ua["ceiling_shared_datapath_note"] = (
-                    f"1 / (flop / peak + {GRAM_VALU_US_N4096} us Gram + {ITE_MEAN_VALU_US_N4096} us MeanITE of pure fp64 VALU "
-                    "issue time per sample at 2.4 GHz, SQ_ACTIVE_INST_VALU of profiles/r04_pmc_gram.md and "
-                    "r04_pmc_ite_mean.md): the MFMA-only ceiling ignores that both instruction classes use the same fp64 units")
+                gus, gnote = measured_constant("gram_valu_us_n4096")
+                ius, inote = measured_constant("ite_mean_valu_us_n4096")
+                if gus is None or ius is None:
+                    ua["ceiling_shared_datapath_units_per_s"] = None
+                    ua["ceiling_shared_datapath_note"] = gnote if gus is None else inote
+                else:
+                    ua["ceiling_shared_datapath_units_per_s"] = 1.0 / (flop_a / (FP64_PEAK_TFLOPS * 1e12) + (gus + ius) * 1e-6)
+                    ua["ceiling_shared_datapath_note"] = (
+                        f"1 / (flop / peak + {gus:.1f} us Gram + {ius:.1f} us MeanITE of pure fp64 VALU issue time per sample at "
+                        "2.4 GHz: SQ_ACTIVE_INST_VALU x 4 clocks / 1024 SIMDs per 1,024-sample launch, " + gnote + "): the "
+                        "MFMA-only ceiling ignores that both instruction classes use the same fp64 units")
             out["units"]["A"] = ua
         if world > 1:
             out["units"] = "N=1 only (units B / C and the unit-A ceilings are single-GPU measurements: run without --gpus)"
@@ -750,9 +868,14 @@ def main():
                                          "1k posterior samples = ONE gpslc_predict_dev call per step (S = 1000: one chunk, "
                                          "a chain of dependent launches with nothing else in flight), fp64, unit A with "
                                          "MeanITE, L=1; kernel launches per call: profiles/r04_c2_literal_kernel_stats.md"),
+                "c3_literal": run_config(gp, synth, np, torch, dev, local_rank, 4096, 8, 2, 5000, 1, False, False, 1, 1,
+                                         "BASELINE configs[2] AS STATED: Synthetic N=4096 D=8 nU=2, 5k posterior samples = ONE "
+                                         "gpslc_predict_dev call per step (S = 5000: five internal chunks of <= 1,024 matrices), "
+                                         "fp64, unit A with MeanITE, L=1"),
                 "c5": run_config(gp, synth, np, torch, dev, local_rank, 16384, 16, 4, 64, 1, True, True, 1, 1,
                                  "BASELINE configs[4] shape on ONE GPU: Synthetic N=16384 D=16 nU=4 binary treatment, "
-                                 "fp32 kernel build + fp64 Cholesky, unit A with MeanITE, doT=1, 64 posterior samples per step"),
+                                 "fp32 kernel build + fp64 Cholesky, unit A with MeanITE, doT=1, 64 posterior samples per step",
+                                 literal_golden=os.path.join(ROOT, "tests", "golden", "config5_literal.npz")),
             }
             for cfg in out["configs"].values():
                 if not cfg["parity"]["ok"]:

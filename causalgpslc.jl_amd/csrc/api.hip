@@ -241,13 +241,6 @@ static int fuse_mode() {
     return m;
 }
 
-// GPSLC_CHAIN (measurement build): the chained in-panel launch (tile_fused_chain_kernel) instead of the three launches per
-// column (diagonal-tile update, diagonal block, strip kernel); measured slower at every size, profiles/r04_ab_experiments.md §3
-static int chain_mode() {       // measurement build only: 1 = diagonal-tile update chained into the strip launch, 2 = + its factorisation
-    static const int m = diag_env("GPSLC_CHAIN", 0);
-    return m < 0 || m > 2 ? 0 : m;
-}
-
 // the diagonal tile (and, with sym == 3, the augmented-row tile) of a symmetric column update, on its own
 static void launch_sym_diag_tiles(const GemmArgs& g, hipStream_t st) {
     GemmArgs d = g;
@@ -326,14 +319,6 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st, int prof_base = 0) {
         // fused panel product: one triangular solve per tile row = 128^2 * 128 multiply-adds... counted as the
         // textbook n^2 b flop of a TRSM (the kernel runs 56 % of the dense 2*128^3 product)
         if (g.fuse) flop += (double)GP_TS * GP_TS * rows * (double)g.nbatch;
-        if (g.chain) {
-            // + the chain items: panel product of the augmented tile of this column, the update of the next diagonal tile
-            // (lower triangle: half a tile product per K tile) with its augmented rows, over [k0, k1]; the 128 x 128
-            // factorisation + inverse are not counted (latency work, 0.1 % of the flops)
-            const double kd = (double)(g.k1 + 1 - g.k0);
-            flop += ((double)GP_TS * GP_TS * g.short_rows
-                     + 2.0 * GP_TS * GP_TS * (0.5 * GP_TS + g.short_rows) * kd) * (double)g.nbatch;
-        }
         {
             ProfScope ps(c, prof_base ? prof_base : (g.fuse ? 1 : 0), flop, st);
             launch_tile_gemm(g, st);
@@ -442,7 +427,6 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
         HC(hipGetLastError());
         return;
     }
-    int diag_ready = 0;       // by the chained launch of column k - 1: 1 = diagonal tile of column k updated, 2 = also factorised
     for (int k = 0; k < nt; ++k) {
         const int ka = (k / pw) * pw;
         const int kend = std::min(ka + pw, nt);
@@ -459,29 +443,16 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
                 // GPSLC_DIAG_FOLD (measurement switch, default on): update + factorisation of the diagonal tile in ONE
                 // launch (diag_update_potrf_kernel) instead of tile_syrk_diag_kernel followed by diag_potrf_inv_v2_kernel
                 static const int fold = diag_env("GPSLC_DIAG_FOLD", 1);
-                const bool fold_ok = fold && diag_ready == 0 && info_div == 1;
+                const bool fold_ok = fold && info_div == 1;
                 if (fold_ok) {
                     GemmArgs d = g;
                     d.F = invref; d.info = info; d.info_base = info_base;
                     launch_diag_update_potrf(d, g.sym == 3 && short_rows > 0, st);
                 } else {
-                    if (diag_ready < 1) launch_sym_diag_tiles(g, st);
-                    if (diag_ready < 2) launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
+                    launch_sym_diag_tiles(g, st);
+                    launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
                 }
-                diag_ready = 0;
                 g.fuse = 1; g.F = invref; g.fk = k;
-                // Chained launch: the work item of tile (k+1, k) also prepares column k + 1 of the same panel — update of
-                // the diagonal tile (k+1, k+1) with the augmented rows riding along, its factor and inverse (k_tilegemm.hip).
-                // Needs the sym == 3 arrangement (augmented tile updated with the diagonal item, <= 32 live rows) or no
-                // augmented row at all.
-                const bool aug_ok = (ntot == nt) || (g.sym == 3);
-                if (chain_mode() && aug_ok && k + 1 < kend && info_div == 1) {
-                    g.chain = chain_mode();
-                    g.i0 = k + 1; g.mi = nt - k - 1; g.ntiles = g.mi;      // items: the chain + tiles (k+2 .. nt-1, k)
-                    g.sym = 0;
-                    g.info = info; g.info_base = info_base;
-                    diag_ready = g.chain;
-                }
                 gemm(c, g, st, prof_base);
                 fused = true;
             } else {
@@ -548,7 +519,11 @@ int auto_batch(gpslc_ctx* c, int64_t S, size_t per_sample_bytes, size_t fixed_by
     HC(hipMemGetInfo(&free_b, &tot_b));
     size_t have = 0;
     for (auto& a : c->arenas) have += a.bytes;
-    const double budget = 0.70 * ((double)free_b + (double)have) / c->nstreams - (double)fixed_bytes;
+    // the AUTOMATIC chunk also stays under 30 % of the device's memory (arenas never shrink, and the host process usually
+    // shares the device: torch's caching allocator under sharded.py / bench.py, other contexts of gpslc_predict_multi on one
+    // GPU); 1,024 matrices at N = 4096 are 28 %.  gpslc_set_tuning(max_batch) may ask for more: then only what is free counts.
+    double budget = 0.70 * ((double)free_b + (double)have) / c->nstreams - (double)fixed_bytes;
+    if (c->max_batch <= 0) budget = std::min(budget, 0.30 * (double)tot_b / c->nstreams - (double)fixed_bytes);
     long long cap = (long long)(budget / (double)per_sample_bytes);
     if (cap < 1) throw std::bad_alloc();
     b = std::min(b, cap);

@@ -98,12 +98,7 @@ struct GemmArgs {
     int fk;
     int skip_gdiag;   // the (short) augmented diagonal tile (short_row0, short_row0) is not an item of this launch: nobody
                       // reads -R R^T (EpiArgs::from_rows)
-    int chain;        // fuse launches only: tile_fused_chain_kernel — item 0 of every batch element is a CHAIN: tile (i0, j0),
-                      // the augmented-row tile (short_row0, j0) (panel product only), then the update of diagonal tile
-                      // (i0, i0) over [k0, k1] (with the augmented tile (short_row0, i0) riding along), its Cholesky and
-                      // inverse (F tile (0, i0), info / info_base as launch_diag): the next column's launch finds its
-                      // diagonal block ready.  Items t >= 1 are the tiles (i0 + t, j0).
-    int* info;        // chain launches: per-batch-element info words and the code base of tile row 0 (launch_diag's)
+    int* info;        // launch_diag_update_potrf: per-batch-element info words and the code base of tile row 0 (launch_diag's)
     int info_base;
     int* queue;       // optional: 16 zero-initialised ints (per-XCD ticket counters [0..8), exit counters [8..16))
                       // owned by the launching stream; the kernel leaves them zeroed again.  null = static stride
@@ -157,7 +152,7 @@ struct RhsArgs {
     const double* part; double* bsum; double* ksum; double* sumdelta;  // bsum/ksum [b][Np], sumdelta [b][L]
     TRef M;
     int live_rows;   // > 0 (single augmented tile row of <= 32 right-hand sides, epilogue sums from the rows of R): only the
-                     // first live_rows (a multiple of 16, <= 32) rows of the augmented tiles are written and the augmented
+                     // first 32 rows of the augmented tiles are written (right-hand sides, then zeros) and the augmented
                      // diagonal tile not at all — every reader of those tiles touches the live 16- / 32-row blocks only
 };
 void launch_rhs(const RhsArgs& r, int nbatch, hipStream_t st);

@@ -318,11 +318,13 @@ __global__ __launch_bounds__(256) void rhs_tiles_kernel(RhsArgs a) {
     const double wt = 1.0 / (tl * tl);
     // element (row q, col c) at c*128 + q; thread -> consecutive q for coalescing
     if (a.live_rows > 0) {
-        // 32 live rows at most: 32 x 128 elements, 256 contiguous bytes per column (the other 96 rows of the tile keep
-        // whatever the workspace held: no kernel reads them, and a row of an MFMA product depends on its own row only)
+        // 32 live rows at most: 32 x 128 elements, 256 contiguous bytes per column.  ALL 32 rows are written (zeros beyond
+        // the last right-hand side): the strip and trailing kernels handle these tiles in 32-row units, so wave 0 loads,
+        // multiplies and stores rows 16..31 even when only 16 are live — they must not hold what a reused arena left there
+        // (NaN / Inf).  The other 96 rows keep whatever the workspace held: no kernel touches them, and a row of an MFMA
+        // product depends on its own row only.
         for (int idx = tid; idx < 32 * GP_TS; idx += 256) {
             const int c = idx >> 5, q = idx & 31;
-            if (q >= a.live_rows) continue;
             const int gj = j * GP_TS + c;
             double v = 0.0;
             if (gj < a.n) {
@@ -387,6 +389,42 @@ __global__ __launch_bounds__(256) void epilogue_kernel(EpiArgs e) {
         const int ncol = e.nt * GP_TS;
         const int nq = (e.meanSATE || e.varSATE) ? e.L : 0;
         if (tid == 0 && e.logdet) e.logdet[s] = ld;
+        auto put = [&](int q, double zw, double ww) {
+            if (q == 0) { if (e.quad) e.quad[s] = ww; return; }
+            const int l = q - 1;
+            const double sd = e.sumdelta[(long long)b * e.L + l];
+            if (e.meanSATE) e.meanSATE[s + e.S * l] = zw / nn;
+            if (e.varSATE) e.varSATE[s + e.S * l] = ((sd - ww) + nn * e.pred_noise) / (nn * nn);
+        };
+        if (nq >= 16) {
+            // Level sweeps: a lane reads 16 CONSECUTIVE right-hand sides of its column with each visit (one full 128-byte line)
+            // instead of one 8-byte element per pass over the columns (a 1 KiB lane stride, once per q: up to 127 uncoalesced
+            // passes per matrix).  Same lane -> column assignment, same fma order along the columns and the same butterfly per
+            // q as the loop below: bit-identical sums.  Wave w takes the blocks q = 16 (w + 4 j) ...
+            for (int qb = 16 * wave; qb <= nq; qb += 64) {
+                double zw[16], ww[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { zw[j] = 0.0; ww[j] = 0.0; }
+                for (int i = lane; i < ncol; i += 64) {
+                    const double* col = tref_tile(e.M, b, e.nt, i >> 7) + (long long)(i & 127) * GP_TS;
+                    const double z = col[0];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const double w = col[qb + j];
+                        zw[j] = fma(z, w, zw[j]);
+                        ww[j] = fma(w, w, ww[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    double a = zw[j], c = ww[j];
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+                    if (lane == 0 && qb + j <= nq) put(qb + j, a, c);
+                }
+            }
+            return;
+        }
         for (int q = wave; q <= nq; q += 4) {
             double zw = 0.0, ww = 0.0;
             for (int i = lane; i < ncol; i += 64) {
@@ -397,15 +435,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(EpiArgs e) {
             }
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) { zw += __shfl_xor(zw, o, 64); ww += __shfl_xor(ww, o, 64); }
-            if (lane == 0) {
-                if (q == 0) { if (e.quad) e.quad[s] = ww; }
-                else {
-                    const int l = q - 1;
-                    const double sd = e.sumdelta[(long long)b * e.L + l];
-                    if (e.meanSATE) e.meanSATE[s + e.S * l] = zw / nn;
-                    if (e.varSATE) e.varSATE[s + e.S * l] = ((sd - ww) + nn * e.pred_noise) / (nn * nn);
-                }
-            }
+            if (lane == 0) put(q, zw, ww);
         }
         return;
     }

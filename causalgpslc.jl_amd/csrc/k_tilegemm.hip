@@ -610,26 +610,15 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Chained in-panel column (round 4) — MEASUREMENT BUILD ONLY (-DGPSLC_DIAG, GPSLC_CHAIN=1|2): built, parity-green, and
-// SLOWER than the three launches it replaces at every size (profiles/r04_ab_experiments.md §3); kept for the A/B record.
-// Left-looking column k used to be three dependent launches: the update of the diagonal
-// tile (tile_syrk_diag_kernel), its Cholesky + inverse (diag_potrf_inv_v2_kernel: one workgroup per matrix, a latency
-// chain of 8 x 16 pivots that leaves the MFMA pipe idle — 9 % of the GPU time at N = 1024) and the strip kernel above.
-// Two of the three are latency bound and nothing can run beside them: the persistent tile kernels own every workgroup
-// slot (two HIP streams + free slots: +1.7 %, profiles/r04_ab_experiments.md).  Here the launch of column k also PREPARES
-// column k + 1: the workgroup that finishes tile (k+1, k) — the last missing operand of the diagonal update of column
-// k + 1 — goes on, inside the same work item, to
-//     (aug, k)            panel product of the augmented right-hand-side tile of column k (short: live rows only)
-//     C(k+1, k+1) -= sum_{kk in [k0, k]} L(k+1, kk) L(k+1, kk)^T        lower triangle, 9 sub-tiles per wave
-//     C(aug, k+1) -= sum_kk L(aug, kk) L(k+1, kk)^T                     the augmented rows ride along (MT row blocks)
-//     L(k+1, k+1), inv(L(k+1, k+1))                                     on the packed image the update leaves in LDS
-// while the other workgroups — its partner on the CU first of all — stream the remaining tiles of column k through the
-// MFMA pipe.  One launch per column; the diagonal tile never makes its HBM round trip between update and factorisation.
-// Every operand of the chain is either final before the launch or written by this very workgroup (release fence +
-// barrier + acquire fence before it is read back through L2).  Arithmetic and summation orders are those of the
-// three kernels it replaces (same device functions / same MFMA chains): the factor is bit-identical.
+// Update of a diagonal tile INSIDE a panel, one wave's share: tile (td, td) -= sum_{kk in [g.k0, kd1)} A(td, kk) A(td, kk)^T,
+// lower triangle, 9 sub-tiles per wave, the augmented right-hand-side rows (MT row blocks) riding along — and the result left
+// as the PACKED LDS IMAGE the factorisation of diag_block.h works on, so that diag_update_potrf_kernel below goes from the
+// update to the Cholesky + inverse without the tile's HBM round trip.  Same arithmetic and summation order as
+// tile_syrk_diag_kernel (syrk_diag_wave below): the factor is bit-identical to the two-launch form.
+// (The round-4 experiment that chained this INTO the strip kernel's launch — one launch per column, measured slower at every
+// size — lives in profiles/r04_chain_experiment.patch, not in the sources.)
 // ---------------------------------------------------------------------------------------
-template <int W, int MT, bool TOLDS>
+template <int W, int MT>
 __device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, const int td, const int kd1, double* smem,
                                                 const int tid, const int lane) {
     // diagonal tile (td, td) -= sum_{kk in [g.k0, kd1)} A(td, kk) A(td, kk)^T -> packed LDS image (smem); augmented tile
@@ -730,7 +719,7 @@ __device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, 
             lds_barrier();
         }
     }
-    if (TOLDS) {
+    {
         // the staging buffers are dead (last barrier): the updated lower blocks become the packed image of the factorisation
         // — block (i, j) at ((i (i + 1) / 2 + j) << 8), element (r, c) at c * 16 + r; acc[v] = element (li, lg + 4 v)
 #pragma unroll
@@ -741,15 +730,6 @@ __device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, 
         for (int cb = 0; cb < 8 - W; ++cb)
 #pragma unroll
             for (int v = 0; v < 4; ++v) smem[((((7 - W) * (8 - W)) / 2 + cb) << 8) + (lg + 4 * v) * 16 + li] = a1c[cb][v];
-    } else {     // back to the tile: the diagonal-block kernel factorises it in the next launch
-#pragma unroll
-        for (int cb = 0; cb <= W; ++cb)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) Cd[(16 * cb + 4 * v) * GP_TS + 16 * W] = a0c[cb][v];
-#pragma unroll
-        for (int cb = 0; cb < 8 - W; ++cb)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) Cd[(16 * cb + 4 * v) * GP_TS + 16 * (7 - W)] = a1c[cb][v];
     }
     if (MT > 0) {
 #pragma unroll
@@ -766,7 +746,7 @@ __device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, 
 // Diagonal tile of an in-panel column in ONE launch (round 4): update of tile (k, k) over [k0, k1) with the
 // augmented rows riding along (what tile_syrk_diag_kernel<MT> does for it), then — on the packed image the update leaves in
 // LDS, without the HBM round trip of the tile — its Cholesky + inverse (what diag_potrf_inv_v2_kernel does).  One workgroup
-// per matrix, two per CU.  Unlike the chained STRIP launch below this pairs the factorisation's fp64 pivot chains with the
+// per matrix, two per CU.  This pairs the factorisation's fp64 pivot chains with the
 // diagonal update's sparse MFMA stream (9 MFMAs per wave and k-step between staging waits), not with a dense one.
 // ---------------------------------------------------------------------------------------
 template <int MT>
@@ -776,10 +756,10 @@ __global__ __launch_bounds__(256, 2) void diag_update_potrf_kernel(GemmArgs g) {
     const int b = blockIdx.x;
     const int td = g.i0;
     switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
-        case 0: syrk_chain_wave<0, MT, true>(g, b, td, g.k1, smem, tid, lane); break;
-        case 1: syrk_chain_wave<1, MT, true>(g, b, td, g.k1, smem, tid, lane); break;
-        case 2: syrk_chain_wave<2, MT, true>(g, b, td, g.k1, smem, tid, lane); break;
-        default: syrk_chain_wave<3, MT, true>(g, b, td, g.k1, smem, tid, lane); break;
+        case 0: syrk_chain_wave<0, MT>(g, b, td, g.k1, smem, tid, lane); break;
+        case 1: syrk_chain_wave<1, MT>(g, b, td, g.k1, smem, tid, lane); break;
+        case 2: syrk_chain_wave<2, MT>(g, b, td, g.k1, smem, tid, lane); break;
+        default: syrk_chain_wave<3, MT>(g, b, td, g.k1, smem, tid, lane); break;
     }
     diag_potrf_inv_v2_body(smem, tref_tile(g.C, b, td, td), tref_tile(g.F, b, 0, td), g.info + b, g.info_base + GP_TS * td,
                            tid, true);
@@ -802,100 +782,6 @@ void launch_diag_update_potrf(const GemmArgs& g, int carry_aug, hipStream_t st) 
     else if (mt == 1) launch_diag_update_potrf_t<1>(g, st);
     else launch_diag_update_potrf_t<2>(g, st);
 }
-
-#ifdef GPSLC_DIAG
-#define CHAIN_LDS_BYTES (DIAG2_LDS_BYTES > GEMM_LDS_BYTES ? DIAG2_LDS_BYTES : GEMM_LDS_BYTES)
-
-template <int WD, int MT, bool POTRF>
-__global__ __launch_bounds__(256, 2) void tile_fused_chain_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lg = lane >> 4;
-    double* lA = smem;                       // [2][KS][LROW]
-    double* lB = smem + 2 * OPER_LDS;        // [2][KS][LROW]
-
-    const long long W = (long long)g.ntiles * g.nbatch;
-    const int G = gridDim.x;
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int gx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
-    const long long wq = W >> 3, wrm = W & 7;
-    const long long x0 = xcd * wq + (xcd < wrm ? xcd : wrm);
-    const long long xc = wq + (xcd < wrm ? 1 : 0);
-
-    const int frow_a = lg * LROW + 32 * wave + li;
-    const int frow_b = lg * LROW + li;
-    int loff[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int q = tid + 256 * u;
-        loff[u] = (q >> 6) * LROW + (q & 63) * 2;
-    }
-    const int nslab = (g.k1 - g.k0) * (GP_TS / KS);
-
-    __shared__ int s_ticket;
-    long long it = local;
-    while (it < xc) {
-        int ticket = 0;
-        if (g.queue && tid == 0) ticket = atomicAdd(&g.queue[xcd], 1);
-        // batch-major item order: the chains are spread evenly over the launch (all chains first — longest items first —
-        // measured WORSE: the diagonal-tile updates, 9 MFMAs per wave and k-step, then run beside each other instead of
-        // beside MFMA-dense strip items)
-        const long long item = x0 + it;
-        const int b = (int)(item / g.ntiles);
-        const int t = (int)(item - (long long)b * g.ntiles);
-        // t == 0 is the chain: tile (k+1, k), then the augmented tile of column k (panel product only: updated by the
-        // previous chain or by the launch before it); one call site, so the item body is instantiated once
-        const int nsub = (t == 0 && MT > 0) ? 2 : 1;
-        for (int sub = 0; sub < nsub; ++sub) {
-            const int ti = sub == 1 ? g.short_row0 : g.i0 + t;
-            strip_item<WD>(g, b, ti, g.j0, sub == 1 || nslab == 0, nslab, lA, lB, tid, lane, wave, li, lg, frow_a, frow_b,
-                           loff, item);
-        }
-        if (t == 0) {
-            const int td = g.i0;                               // the next column: k + 1
-            // L(k+1, k) and L(aug, k) were stored by this workgroup: make them visible to all of its waves through L2
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            switch (wave) {
-                case 0: syrk_chain_wave<0, MT, POTRF>(g, b, td, g.k1 + 1, smem, tid, lane); break;
-                case 1: syrk_chain_wave<1, MT, POTRF>(g, b, td, g.k1 + 1, smem, tid, lane); break;
-                case 2: syrk_chain_wave<2, MT, POTRF>(g, b, td, g.k1 + 1, smem, tid, lane); break;
-                default: syrk_chain_wave<3, MT, POTRF>(g, b, td, g.k1 + 1, smem, tid, lane); break;
-            }
-            if (POTRF)   // (the first barrier of the factorisation publishes the image)
-                diag_potrf_inv_v2_body(smem, tref_tile(g.C, b, td, td), tref_tile(g.F, b, 0, td), g.info + b,
-                                       g.info_base + GP_TS * td, tid, true);
-        }
-        if (g.queue) {
-            if (tid == 0) s_ticket = ticket;
-            __syncthreads();
-            it = (long long)gx + s_ticket;
-            __syncthreads();
-        } else {
-            it += gx;
-        }
-    }
-    if (g.queue && tid == 0) {
-        __threadfence();
-        if (atomicAdd(&g.queue[8 + xcd], 1) == gx - 1) {
-            g.queue[xcd] = 0;
-            g.queue[8 + xcd] = 0;
-        }
-    }
-}
-
-template <int MT, bool POTRF>
-static void launch_chain_t(const GemmArgs& g, unsigned grid, hipStream_t st) {
-    static DeviceOnce once;
-    const int bytes = POTRF ? CHAIN_LDS_BYTES : GEMM_LDS_BYTES;
-    lds_opt_in(once, (const void*)tile_fused_chain_kernel<FUSE_WD, MT, POTRF>, bytes);
-    hipLaunchKernelGGL((tile_fused_chain_kernel<FUSE_WD, MT, POTRF>), dim3(grid), dim3(256), bytes, st, g);
-}
-
-#endif  // GPSLC_DIAG (chained in-panel column)
 
 // ---------------------------------------------------------------------------------------
 // Diagonal tiles of a symmetric update:  C(t, t) -= sum_kk A(t, kk) A(t, kk)^T, lower triangle only.
@@ -1100,19 +986,6 @@ void launch_tile_gemm(const GemmArgs& g, hipStream_t st) {
     }
     if (g.diag_skip == 2) {
         if (g.accumulate) launch_one<1, 2>(g, grid, st); else launch_one<0, 2>(g, grid, st);
-        return;
-    }
-#endif
-#ifdef GPSLC_DIAG
-    if (g.fuse && g.accumulate && g.chain) {
-        const int mt = g.short_rows > 0 ? (g.short_rows + 15) / 16 : 0;     // callers chain only for mt <= 2
-        if (g.chain >= 2) {      // GPSLC_CHAIN=2: the diagonal block factorised inside the chain too
-            if (mt == 0) launch_chain_t<0, true>(g, grid, st);
-            else if (mt == 1) launch_chain_t<1, true>(g, grid, st);
-            else launch_chain_t<2, true>(g, grid, st);
-        } else if (mt == 0) launch_chain_t<0, false>(g, grid, st);
-        else if (mt == 1) launch_chain_t<1, false>(g, grid, st);
-        else launch_chain_t<2, false>(g, grid, st);
         return;
     }
 #endif

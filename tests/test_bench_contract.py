@@ -48,6 +48,34 @@ def test_pmc_summary_is_tied_to_the_kernel_source():
     assert bench.pmc_traffic(False)[0] is None
 
 
+def test_measured_constants_are_withheld_when_their_sources_change(tmp_path, monkeypatch):
+    """VERDICT r04 weak #12 / ADVICE r04: the HBM bytes per sample of config 2 and the fp64-VALU issue times of the Gram build and
+    the MeanITE pass are measurements; bench.py reads them from a committed file stamped with the git blob hashes of the
+    sources they were taken on and withholds them on a mismatch, like roofline.traffic."""
+    sys.path.insert(0, ROOT)
+    import bench
+    src = os.path.join("causalgpslc.jl_amd", "csrc", "k_gram.hip")
+    good = bench.git_blob_sha(os.path.join(ROOT, src))
+    f = tmp_path / "constants.json"
+    f.write_text(json.dumps({"gram_valu_us_n4096": {"value": 17.0, "source_shas": {src: good}, "from": "profiles/x.md"},
+                             "stale": {"value": 1.0, "source_shas": {src: "0" * 40}, "from": "profiles/y.md"}}))
+    monkeypatch.setattr(bench, "BENCH_CONSTANTS", str(f))
+    v, note = bench.measured_constant("gram_valu_us_n4096")
+    assert v == 17.0 and "match" in note
+    v, note = bench.measured_constant("stale")
+    assert v is None and "STALE" in note and "k_gram.hip" in note
+    assert bench.measured_constant("absent")[0] is None
+    monkeypatch.setattr(bench, "BENCH_CONSTANTS", str(tmp_path / "nope.json"))
+    assert bench.measured_constant("gram_valu_us_n4096")[0] is None
+    # the committed file, when present, must name only sources that exist
+    real = os.path.join(ROOT, "profiles", "r05_bench_constants.json")
+    if os.path.exists(real):
+        for name, rec in json.load(open(real)).items():
+            assert rec["value"] > 0 and rec["source_shas"], name
+            for rel in rec["source_shas"]:
+                assert os.path.exists(os.path.join(ROOT, rel)), (name, rel)
+
+
 def test_launcher_counts_gpus_without_touching_them():
     sys.path.insert(0, ROOT)
     import bench
