@@ -565,8 +565,12 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                + 1024;
     int Bb_target = 0;
     if (unitB) {
-        // unit-B sub-batch: 64 units at N = 4096 (203 MB each); larger buys nothing (measured)
-        Bb_target = (int)std::max<long long>(1, std::min<long long>(128, 65536LL / ((long long)nt * nt)));
+        // unit-B sub-batch: 128 units at N = 4096 (203 MB each, 26 GB).  Round 5, 256 units of 8 samples x 32 levels on one box
+        // (profiles/r05_ab_experiments.md §3): 16 / 32 / 64 / 128 / 256 per sub-batch -> 322 / 349 / 364 / 372 / 373 units/s —
+        // the late columns of a factorisation have (nt - k) x sub-batch items for 512 workgroup slots; flat from 128 on
+        Bb_target = (int)std::max<long long>(1, std::min<long long>(128, 131072LL / ((long long)nt * nt)));
+        static const int bb_env = diag_env("GPSLC_UNITB_BATCH", 0);      // measurement switch: the sub-batch curve (profiles/r05)
+        if (bb_env > 0) Bb_target = bb_env;
     }
     // draws: normals workspace of one level of the sub-batch + the level-sweep staging buffer (see the unit-B loop)
     // (per unit of the sub-batch: the staging buffer holds max(1, Bb / L) samples x L levels <= Bb pairs, or one sample's

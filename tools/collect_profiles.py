@@ -39,6 +39,49 @@ for a, b in {"pmc_tile_gemm.json": f"{rnd}_pmc_tile_gemm.json", "pmc_fused.json"
     d["note"] = ("FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate rocprofv3 --pmc passes, "
                  f"tools/profile_{rnd}.sh; per-launch means")
     json.dump(d, open(os.path.join(dst, b), "w"), indent=1)
+# ---- measured constants bench.py quotes (round 5): each stamped with the git blob hashes of the sources it was measured on;
+# bench.measured_constant withholds a figure whose sources have changed since
+CS = os.path.join("causalgpslc.jl_amd", "csrc")
+
+
+def shas(*files):
+    return {os.path.join(CS, f): blob_sha(os.path.join(ROOT, CS, f)) for f in files}
+
+
+consts_path = os.path.join(dst, f"{rnd}_bench_constants.json")
+consts = json.load(open(consts_path)) if os.path.exists(consts_path) else {}
+for key, fn, files in (("gram_valu_us_n4096", "pmc_gram.json", ("k_gram.hip", "gp_math.h")),
+                       ("ite_mean_valu_us_n4096", "pmc_ite_mean.json", ("k_solve.hip", "gp_math.h"))):
+    f = os.path.join(src, fn)
+    if os.path.exists(f):
+        d = json.load(open(f)).get("SQ_ACTIVE_INST_VALU")
+        if d:
+            # wave-instruction issue cycles summed over the chip: x 4 clocks per fp64 wave instruction / 1,024 SIMDs / 1,024
+            # samples per launch / 2.4 GHz
+            us = d["sum"] / d["launches"] * 4.0 / 1024.0 / 1024.0 / 2.4e9 * 1e6
+            consts[key] = {"value": us, "source_shas": shas(*files), "from": f"profiles/{rnd}_{fn.replace('.json', '.md')}",
+                           "what": "fp64 VALU issue time per posterior sample at N=4096 D=8 nU=2 (SQ_ACTIVE_INST_VALU x 4 / 1024 "
+                                   "SIMDs / 1024 samples / 2.4 GHz)"}
+c2dir = os.path.join(src, "c2json")
+if os.path.isdir(c2dir):
+    tot, per = 0.0, {}
+    for fn in sorted(os.listdir(c2dir)):
+        d = json.load(open(os.path.join(c2dir, fn)))
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            b = (2.0 * d["FETCH_SIZE"]["sum"] + d["WRITE_SIZE"]["sum"]) * 1024.0      # KB -> B, FETCH_SIZE doubled (gfx950)
+            per[d["kernel"]] = b
+            tot += b
+    samples = 4 * 8192          # tools/profile script: 1 warm-up + 3 timed steps of 8,192 posterior samples
+    if tot > 0:
+        consts["c2_hbm_bytes_per_sample"] = {
+            "value": tot / samples, "samples_per_step": 8192,
+            "source_shas": shas("k_tilegemm.hip", "k_gram.hip", "k_solve.hip", "k_diag.hip", "diag_block.h", "api.hip"),
+            "from": f"profiles/{rnd}_pmc_n1024_per_kernel.md",
+            "per_kernel_bytes_per_sample": {k: v / samples for k, v in per.items()},
+            "what": "HBM bytes per posterior sample at BASELINE config 2 (N=1024 D=4 nU=1, 8,192 samples per step): FETCH_SIZE x 2 "
+                    "+ WRITE_SIZE summed over every kernel of the step"}
+if consts:
+    json.dump(consts, open(consts_path, "w"), indent=1)
 for l in open(os.path.join(src, "trace.log")) if os.path.exists(os.path.join(src, "trace.log")) else []:
     if l.startswith('{"metric"'):
         open(os.path.join(dst, f"{rnd}_bench_under_rocprof.json"), "w").write(l)
