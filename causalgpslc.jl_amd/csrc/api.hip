@@ -575,11 +575,13 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
     // draws: normals workspace of one level of the sub-batch + the level-sweep staging buffer (see the unit-B loop)
     // (per unit of the sub-batch: the staging buffer holds max(1, Bb / L) samples x L levels <= Bb pairs, or one sample's
     // L > Bb levels — sized below through the extra term)
-    // spp <= 16: the streaming draw kernel reads the unit's normals (caller's or Philox) from an operand image of
-    // 16 Np doubles (DrawArgs::zt) instead
+    // spp <= 128: the streaming draw kernel reads the unit's normals (caller's or Philox) from an operand image of
+    // 16 Np doubles per block of 16 draws (DrawArgs::zt) instead
     static const int draws_stream = diag_env("GPSLC_DRAWS_STREAM", 1);      // measurement switch: 0 = the LDS-staged kernel of rounds 2-4
-    const bool zimage = want_draws && io.spp <= 16 && draws_stream;
-    const size_t draws_per = want_draws ? ((zimage ? (size_t)16 * Np * 8 + 256 : (io.z ? 0 : (size_t)io.spp * n * 8 + 256)) +
+    const bool zimage = want_draws && io.spp <= 128 && draws_stream;
+    // per unit: 1 / 2 / 4 / 8 blocks of 16 draws (draws_nq, k_solve.hip: the stream kernel's template parameter)
+    const size_t zimage_doubles = zimage ? (size_t)16 * (io.spp <= 16 ? 1 : io.spp <= 32 ? 2 : io.spp <= 64 ? 4 : 8) * Np : 0;
+    const size_t draws_per = want_draws ? ((zimage ? zimage_doubles * 8 + 256 : (io.z ? 0 : (size_t)io.spp * n * 8 + 256)) +
                                            (L > 1 ? (size_t)io.spp * n * 8 + 256 : 0)) : 0;
     const size_t unitB_all = unitB_per + draws_per;
     const size_t dtmp_extra = (want_draws && L > Bb_target) ? (size_t)(L - Bb_target) * io.spp * n * 8 : 0;
@@ -705,7 +707,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
             // draws: the library's own normals of one sub-batch (generated once per unit), and for a level sweep the
             // staging buffer [sample][level][d][i] that is rearranged into the level-fastest tensor sample group by group
             double* zgen = (want_draws && !io.z && !zimage) ? ar.take<double>((size_t)Bb * io.spp * n) : nullptr;
-            double* zt = zimage ? ar.take<double>((size_t)Bb * 16 * Np) : nullptr;
+            double* zt = zimage ? ar.take<double>((size_t)Bb * zimage_doubles) : nullptr;
             double* dtmp = (want_draws && L > 1) ? ar.take<double>((size_t)gs_max * L * io.spp * n) : nullptr;
             const long long wbs = (long long)nt * nt * GP_TSQ, cbs = nlow * GP_TSQ;
             for (int g0 = 0; g0 < nb; g0 += gs_max) {

@@ -213,9 +213,9 @@ struct DrawArgs {
     int lc;
     const double* mean;   // meanITE n x S x L
     const double* z;      // caller's normals, n x spp x S x L, or null
-    double* zgen;         // z == null, spp > 16: workspace [nbatch][spp][n] the library's Philox normals are generated into
-    double* zt;           // spp <= 16: workspace [nbatch][16 nt 128] — the unit's normals (caller's or Philox) in the MFMA
-                          // operand image the streaming draw kernel reads (draws_zt_index, k_solve.hip), zero-padded
+    double* zgen;         // z == null, spp > 128: workspace [nbatch][spp][n] the library's Philox normals are generated into
+    double* zt;           // spp <= 128: workspace [nbatch][1 | 2 | 4 | 8 blocks of 16 draws][16 nt 128] — the unit's normals (caller's or Philox) in
+                          // the MFMA operand image the streaming draw kernel reads (draws_zt_index, k_solve.hip), zero-padded
     unsigned long long seed;
     long long rs0, rS;    // Philox stream of batch element b: (rs0 + b / lc) + rS * (l + b % lc) (gpslc_set_ensemble)
     // element (instance i, sample offset sb = b / lc, level offset lb = b % lc, draw d) of this launch goes to

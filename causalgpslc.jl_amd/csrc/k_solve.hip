@@ -723,7 +723,8 @@ __global__ __launch_bounds__(256) void draws_mfma_kernel(DrawArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Round 5: the draws of a unit with spp <= 16 (the reference's default is 10) as a PURE STREAM of L_c.
+// Round 5: the draws of a unit with spp <= 128 (the reference's default is 10; NQ = 1, 2, 4 or 8 blocks of 16 draws per pass;
+// more than 128 draws keep the LDS-staged multi-pass kernel above) as a PURE STREAM of L_c.
 // What the LDS kernel above left on the table (4.3 of the ~6 TB/s a read-only sweep reaches on this chip): its 4 waves
 // meet at two barriers per 64 columns (one wave's late line stalls four), its work items span 1..nt tiles (the last long
 // row runs alone at the end of the launch), and the diagonal tile is read whole.  Here
@@ -740,6 +741,8 @@ __global__ __launch_bounds__(256) void draws_mfma_kernel(DrawArgs a) {
 // MFMA operands, accumulators and the order of the k groups along a row are those of draws_mfma_kernel<1>: the chains
 // are the same, so the draws are bit-identical (skipped groups of the diagonal tile only ever added +-0).
 // ---------------------------------------------------------------------------------------
+// blocks of 16 draws the stream kernel works on for spp draws per unit: its template parameter NQ
+__host__ __device__ inline int draws_nq(int spp) { return spp <= 16 ? 1 : spp <= 32 ? 2 : spp <= 64 ? 4 : 8; }
 // index of z[column g][draw d] in a unit's operand image (16 * Np doubles)
 __host__ __device__ inline long long draws_zt_index(long long g, int d) {
     return ((g >> 3) << 7) + ((g & 3) << 5) + ((long long)d << 1) + ((g >> 2) & 1);
@@ -750,10 +753,12 @@ __global__ __launch_bounds__(256) void draws_zstage_kernel(DrawArgs a) {
     const long long b = blockIdx.y, sb = b / a.lc, lb = b % a.lc;
     const long long s = a.s0 + sb, lev = a.l + lb;
     const long long n = a.n, Np = (long long)a.nt * GP_TS;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= Np * 8) return;
-    const int d = (int)(t & 15), lq = (int)(t >> 4) & 3;
-    const long long g0 = ((t >> 6) << 3) + lq, g1 = g0 + 4;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // word t of the image; block q of 16 draws = words [q 8 Np, ...)
+    const int nq = draws_nq(a.spp);              // the stream kernel's NQ: every one of its blocks is written (zeros beyond spp)
+    if (t >= Np * 8 * nq) return;
+    const long long tq = t % (Np * 8);
+    const int d = (int)(tq & 15) + 16 * (int)(t / (Np * 8)), lq = (int)(tq >> 4) & 3;
+    const long long g0 = ((tq >> 6) << 3) + lq, g1 = g0 + 4;
     double v0 = 0.0, v1 = 0.0;
     if (d < a.spp) {
         if (a.z) {
@@ -766,12 +771,12 @@ __global__ __launch_bounds__(256) void draws_zstage_kernel(DrawArgs a) {
             if (g1 < n) v1 = philox_normal(a.seed, stream, (unsigned long long)(g1 + n * d));
         }
     }
-    *reinterpret_cast<d2s*>(a.zt + b * Np * 16 + 2 * t) = (d2s){v0, v1};
+    *reinterpret_cast<d2s*>(a.zt + b * Np * 16 * nq + 2 * t) = (d2s){v0, v1};
 }
 
 // CC columns per chunk (CC / 4 k groups of the 16x16x4 MFMA), NS register sets in rotation, WPE waves per SIMD the
 // register allocation is held to
-template <int CC, int NS, int WPE>
+template <int CC, int NS, int WPE, int NQ = 1>
 __global__ __launch_bounds__(256, WPE) void draws_stream_kernel(DrawArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -780,7 +785,7 @@ __global__ __launch_bounds__(256, WPE) void draws_stream_kernel(DrawArgs a) {
     const long long s = a.s0 + sb, lev = a.l + lb;
     const long long n = a.n;
     const long long Np = (long long)a.nt * GP_TS;
-    const double* __restrict__ zt = a.zt + b * Np * 16 + 2 * lane;
+    const double* __restrict__ zt = a.zt + b * Np * 16 * NQ + 2 * lane;      // block q of 16 draws: + q * 16 Np
     const int r0 = 32 * wave + 2 * li;                  // this lane's two rows inside the tile: r0, r0 + 1
     const int p = blockIdx.x;
     constexpr int NL = CC / 4, NZ = CC / 8;             // 16-byte factor / z loads per chunk and lane
@@ -791,25 +796,31 @@ __global__ __launch_bounds__(256, WPE) void draws_stream_kernel(DrawArgs a) {
         // the tiles (ib, 0..ib) of a row are contiguous in both tile layouts
         const double* __restrict__ Lrow = tref_tile(a.Lc, b, ib, 0) + r0 + lq * GP_TS;
         const int nch = (GP_TS / CC) * ib + (32 / CC) * wave + 32 / CC;   // chunks up to and including the wave's diagonal block
-        d4s acc0 = (d4s){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-        d2s lv[NS][NL], zv[NS][NZ];
-        auto load = [&](int c, d2s (&l)[NL], d2s (&z)[NZ]) {
+        d4s acc0[NQ], acc1[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { acc0[q] = (d4s){0.0, 0.0, 0.0, 0.0}; acc1[q] = acc0[q]; }
+        d2s lv[NS][NL], zv[NS][NQ * NZ];
+        auto load = [&](int c, d2s (&l)[NL], d2s (&z)[NQ * NZ]) {
             c = min(c, nch - 1);                         // past the end: the last chunk again (keeps the loop body branch-free)
             const double* __restrict__ zp = zt + (long long)c * (CC * 16);
 #pragma unroll
-            for (int m = 0; m < NZ; ++m) z[m] = *reinterpret_cast<const d2s*>(zp + m * 128);
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int m = 0; m < NZ; ++m) z[q * NZ + m] = *reinterpret_cast<const d2s*>(zp + q * (16 * Np) + m * 128);
             const double* __restrict__ lp = Lrow + (long long)c * (CC * GP_TS);
 #pragma unroll
             for (int kk = 0; kk < NL; ++kk)
                 l[kk] = __builtin_nontemporal_load(reinterpret_cast<const d2s*>(lp + kk * 4 * GP_TS));
         };
-        auto compute = [&](const d2s (&l)[NL], const d2s (&z)[NZ]) {
+        auto compute = [&](const d2s (&l)[NL], const d2s (&z)[NQ * NZ]) {
 #pragma unroll
-            for (int kk = 0; kk < NL; ++kk) {
-                const double zf = (kk & 1) ? z[kk >> 1].y : z[kk >> 1].x;
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, l[kk].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, l[kk].y, acc1, 0, 0, 0);
-            }
+            for (int kk = 0; kk < NL; ++kk)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const double zf = (kk & 1) ? z[q * NZ + (kk >> 1)].y : z[q * NZ + (kk >> 1)].x;
+                    acc0[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, l[kk].x, acc0[q], 0, 0, 0);
+                    acc1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, l[kk].y, acc1[q], 0, 0, 0);
+                }
         };
         // the chunks of the wave's own 32 x 32 diagonal block: only the lower triangle belongs to L_c
         auto mask_diag = [&](d2s (&l)[NL], int c) {
@@ -841,18 +852,20 @@ __global__ __launch_bounds__(256, WPE) void draws_stream_kernel(DrawArgs a) {
                 compute(lv[i % NS], zv[i % NS]);
             }
         }
-        // acc{0,1}[v]: row r0 + {0,1}, draw 4 v + lq
+        // acc{0,1}[q][v]: row r0 + {0,1}, draw 16 q + 4 v + lq
         const long long gi = (long long)ib * GP_TS + r0;
         if (gi < n) {
             const double mu0 = a.mean[gi + n * (s + a.S * lev)];
             const double mu1 = (gi + 1 < n) ? a.mean[gi + 1 + n * (s + a.S * lev)] : 0.0;
             double* __restrict__ ob = a.out + a.obase + sb * a.osb + lb * a.osl + gi * a.osi;
 #pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int dd = 4 * v + lq;
+                const int dd = 16 * q + 4 * v + lq;
                 if (dd < a.spp) {
                     double* o = ob + (long long)dd * a.osd;
-                    const double x0 = mu0 + acc0[v], x1 = mu1 + acc1[v];
+                    const double x0 = mu0 + acc0[q][v], x1 = mu1 + acc1[q][v];
                     if (a.osi == 1 && gi + 1 < n && ((reinterpret_cast<unsigned long long>(o) & 15ull) == 0)) {
                         *reinterpret_cast<d2s*>(o) = (d2s){x0, x1};
                     } else {
@@ -902,10 +915,15 @@ static void launch_draws_t(const DrawArgs& a, int nbatch, hipStream_t st) {
     hipLaunchKernelGGL((draws_mfma_kernel<NQ>), dim3(a.nt, nbatch), dim3(256), bytes, st, a);
 }
 void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st) {
-    if (a.spp <= 16 && a.zt) {     // one MFMA pass wide: the barrier-free stream of L_c (round 5)
-        const long long words = (long long)a.nt * GP_TS * 8;
+    if (a.spp <= 128 && a.zt) {    // up to 128 draws = one pass over L_c: the barrier-free stream of L_c (round 5)
+        const long long words = (long long)a.nt * GP_TS * 8 * draws_nq(a.spp);
         hipLaunchKernelGGL(draws_zstage_kernel, dim3((unsigned)((words + 255) / 256), nbatch), dim3(256), 0, st, a);
         const dim3 grid((a.nt + 1) / 2, nbatch);
+        // more than 16 draws: NQ z blocks and accumulator pairs per wave.  HBM-bound up to 32 draws, MFMA-bound beyond (the
+        // factor is still read exactly once): fewer, fatter waves
+        if (a.spp > 64) { hipLaunchKernelGGL((draws_stream_kernel<16, 2, 1, 8>), grid, dim3(256), 0, st, a); return; }
+        if (a.spp > 32) { hipLaunchKernelGGL((draws_stream_kernel<16, 3, 2, 4>), grid, dim3(256), 0, st, a); return; }
+        if (a.spp > 16) { hipLaunchKernelGGL((draws_stream_kernel<16, 3, 3, 2>), grid, dim3(256), 0, st, a); return; }
 #ifdef GPSLC_DIAG
         // measurement build: GPSLC_DRAWS_VAR picks the register-set arrangement, GPSLC_DRAWS_LDS pads the workgroup's LDS
         // allocation (KiB) to pin the number of workgroups per CU

@@ -21,10 +21,13 @@ post = synth.make_posterior(n, D, K, S, obj, seed=1234)
 g = gp.GPSLCObject(X, T, Y, post["U"], post["uyLS"], post["xyLS"], post["tyLS"], post["yNoise"], post["yScale"])
 doTs = synth.levels(T, L)
 gp.predict(g, doTs[:1], spp=spp, seed=1, want_draws=True)     # warm-up (arenas sized for this spp, first touch)
-t0 = time.perf_counter()
-ms, vs, mi, dr = gp.predict(g, doTs, spp=spp, seed=7, want_draws=True)
-dt = time.perf_counter() - t0
-assert np.all(np.isfinite(dr))
 units = S * L
+for rep in range(2):      # the first full-size call also grows the context's workspace (tens of GB of hipMalloc): report both
+    t0 = time.perf_counter()
+    ms, vs, mi, dr = gp.predict(g, doTs, spp=spp, seed=7, want_draws=True)
+    dt = time.perf_counter() - t0
+    if rep == 0:
+        print(f"(first full-size call, workspace growth included: {units / dt:.1f} units/s, {dt * 1e3:.0f} ms)")
+assert np.all(np.isfinite(dr))
 print(f"N={n} S={S} L={L} spp={spp}: {units / dt:.1f} (sample, level) units/s, {units * spp / dt:.0f} draws/s, "
       f"{dt * 1e3:.0f} ms; unit-B ceiling at 78.6 TFLOP/s = {78.6e12 / (7.0 / 3.0 * n ** 3):.0f}/s")
