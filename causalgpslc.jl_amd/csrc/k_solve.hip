@@ -765,6 +765,37 @@ __global__ __launch_bounds__(256) void draws_zstage_kernel(DrawArgs a) {
             const double* __restrict__ zu = a.z + n * a.spp * (s + a.S * lev);
             if (g0 < n) v0 = zu[g0 + n * d];
             if (g1 < n) v1 = zu[g1 + n * d];
+        } else if ((n & 1) == 0) {
+            // n even: the elements e = g + n d and e ^ 1 of a unit's stream share one Philox counter and one Box-Muller
+            // transform (even -> cos, odd -> sin), and the lane that holds column g ^ 1 of the same draw is lane ^ 16 (lq ^ 1).
+            // The even-lq lane evaluates the pair of g0, the odd-lq lane the pair of g1 = g0 + 4, and they swap the halves:
+            // one counter, one log, one sqrt, one sincos per lane instead of two of each — the same values philox_normal()
+            // returns element by element.  (Whole waves reach this point together: Np * 8 * nq is a multiple of 64.)
+            const unsigned long long stream = (unsigned long long)((a.rs0 + sb) + a.rS * lev);
+            const bool odd = (lq & 1) != 0;
+            const long long ge = odd ? (g1 & ~1ll) : g0;            // the even column of the pair this lane evaluates
+            double c = 0.0, sn = 0.0;
+            if (d < a.spp && ge < n) {
+                unsigned w[4];
+                const unsigned long long pair = (unsigned long long)(ge + n * d) >> 1;
+                philox4x32_10((unsigned)pair, (unsigned)(pair >> 32), (unsigned)stream, (unsigned)(stream >> 32),
+                              (unsigned)a.seed, (unsigned)(a.seed >> 32), w);
+                const unsigned long long A = ((unsigned long long)w[0] << 21) ^ ((unsigned long long)w[1] >> 11);
+                const unsigned long long Bq = ((unsigned long long)w[2] << 21) ^ ((unsigned long long)w[3] >> 11);
+                const double u1 = ((double)A + 0.5) * (1.0 / 9007199254740992.0);
+                const double u2 = ((double)Bq + 0.5) * (1.0 / 9007199254740992.0);
+                const double rad = sqrt(-2.0 * log(u1));
+                const double ang = 6.283185307179586476925286766559 * u2;
+                c = rad * cos(ang);
+                sn = rad * sin(ang);
+            }
+            // even-lq lane: keeps cos as its v0 (column g0), sends sin to the partner's v0 (column g0 + 1);
+            // odd-lq lane: keeps sin as its v1 (column g1), sends cos to the partner's v1 (column g1 - 1)
+            const double give = odd ? c : sn;
+            const double got = __shfl_xor(give, 16, 64);
+            if (odd) { v0 = got; v1 = sn; } else { v0 = c; v1 = got; }
+            if (g0 >= n) v0 = 0.0;
+            if (g1 >= n) v1 = 0.0;
         } else {
             const unsigned long long stream = (unsigned long long)((a.rs0 + sb) + a.rS * lev);
             if (g0 < n) v0 = philox_normal(a.seed, stream, (unsigned long long)(g0 + n * d));

@@ -8,16 +8,16 @@ PART=${2:-a}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config4 --no-configs"
+B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-configs"
 UB="python3 $GRAFT_REPO_ROOT/tools/bench_unit_b.py 4096 64 1 10"
-C2="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config4 --no-configs --no-units --n 1024 --d 4 --nu 1 --samples-per-step 8192"
-C2L="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config4 --no-configs --no-units --n 1024 --d 4 --nu 1 --samples-per-step 1000"
+C2="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-configs --no-units --n 1024 --d 4 --nu 1 --samples-per-step 8192"
+C2L="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-configs --no-units --n 1024 --d 4 --nu 1 --samples-per-step 1000"
 KS="python3 $GRAFT_REPO_ROOT/tools/kernel_stats_md.py"
 PS="python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py"
 if [ "$PART" = a ]; then
 # (1) unit A: the bench's timed region, per-kernel durations (HIP-event profiling on, as in the driver's run)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --no-units > $OUT/trace.log 2>&1 &&
-# (2) units B and C: 2 x 64 (sample, level) units with 10 draws each (warm-up call + timed call)
+# (2) units B and C: 64 (sample, level) units with 10 draws each per call (warm-up call + two full-size calls)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_b -- $UB > $OUT/trace_b.log 2>&1 &&
 # (2b) BASELINE config 2 (N = 1024), 8,192 samples per step
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c2 -- $C2 > $OUT/trace_c2.log 2>&1 &&
@@ -28,8 +28,8 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/c2pmc/write -- $C2 --no-profile > $OUT/c2pmc_write.log 2>&1
 grep '"metric"' $OUT/trace.log | cut -c1-300
 tail -1 $OUT/trace_b.log
-$KS $OUT/trace "rocprofv3 --kernel-trace --stats of \`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config4 --no-configs --no-units\` (4 x 1024 posterior samples of unit A at N=4096 D=8 nU=2: 1 warm-up + 3 timed steps)" 4096 > $OUT/kernel_stats.md
-$KS $OUT/trace_b "rocprofv3 --kernel-trace --stats of \`python3 tools/bench_unit_b.py 4096 64 1 10\` (2 x 64 (sample, level) units of B + C at N=4096: warm-up call + timed call, 10 draws per unit)" 0 > $OUT/kernel_stats_unit_b.md
+$KS $OUT/trace "rocprofv3 --kernel-trace --stats of \`python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-configs --no-units\` (4 x 1024 posterior samples of unit A at N=4096 D=8 nU=2: 1 warm-up + 3 timed steps)" 4096 > $OUT/kernel_stats.md
+$KS $OUT/trace_b "rocprofv3 --kernel-trace --stats of \`python3 tools/bench_unit_b.py 4096 64 1 10\` (3 x 64 (sample, level) units of B + C at N=4096: warm-up call + two full-size calls, 10 draws per unit)" 0 > $OUT/kernel_stats_unit_b.md
 $KS $OUT/trace_c2 "rocprofv3 --kernel-trace --stats of the unit-A bench at BASELINE config 2 (N=1024 D=4 nU=1, 4 x 8192 posterior samples: 1 warm-up + 3 timed steps)" 32768 > $OUT/kernel_stats_c2.md
 $KS $OUT/trace_c2l "rocprofv3 --kernel-trace --stats of BASELINE config 2 as stated (N=1024 D=4 nU=1, ONE gpslc_predict_dev call with S = 1000 per step; 4 calls: 1 warm-up + 3 timed): kernel launches per call = calls / 4" 4000 > $OUT/kernel_stats_c2_literal.md
 { echo "## HBM traffic per kernel at BASELINE config 2 (N = 1024, D 4, nU 1; a launch = one chunk of 8,192 posterior samples)"; echo;
