@@ -84,7 +84,7 @@ def test_launcher_counts_gpus_without_touching_them():
 
 
 def test_committed_bench_line_carries_the_contract_keys():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "sate_rel_err", "units"):
         assert k in d, k
@@ -107,6 +107,19 @@ def test_committed_bench_line_carries_the_contract_keys():
     pb = d["units"]["B"]["parity"]
     assert pb["cond"] < 1e8 and pb["draw_tight_bound"] is not None and pb["draw_err"] <= pb["draw_tight_bound"]
     assert d["roofline"]["traffic"] is not None and d["roofline"]["traffic"] > 0
+    # round 5: the spread of the value; config 3 as BASELINE states it (ONE call, S = 5000) within 2 % of the headline; the LITERAL
+    # restatement inside the line for configs 4 and 5; unit C on the streaming draw kernel; measured constants present (not withheld)
+    assert len(d["value_runs"]) == 3 and d["value_runs"][0] == d["value"]
+    assert max(d["value_runs"]) / min(d["value_runs"]) - 1.0 <= 0.02
+    c3l = d["configs"]["c3_literal"]
+    assert c3l["samples_per_step"] == 5000 and c3l["parity"]["ok"] and abs(c3l["value"] / d["value"] - 1.0) <= 0.02
+    lg = d["configs"]["c5"]["parity"]["literal_golden"]
+    assert lg["ok"] and max(lg["mean_rel_err"], lg["var_rel_err"], lg["mean_ite_rel_err"]) < 1e-6 and "LITERAL" in lg["reference"]
+    lu = d["config4"]["parity"]["literal_unit"]
+    assert lu["ok"] and max(lu["mean_rel_err"], lu["var_rel_err"], lu["mean_ite_rel_err"]) < 1e-9
+    assert d["units"]["C"]["frac"] >= 0.65 and d["units"]["B"]["frac"] >= 0.75
+    assert c2["hbm"]["bytes_per_unit"] is not None and "source hashes match" in c2["hbm"]["note"]
+    assert d["units"]["A"]["ceiling_shared_datapath_units_per_s"] is not None
 
 
 def _free_port():
