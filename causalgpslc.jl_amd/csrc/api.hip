@@ -441,7 +441,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
                 // diagonal tile first, then its factor + inverse, then ONE pass over the column: update and panel
                 // product of every tile below the diagonal (the column makes one HBM round trip instead of two)
                 // GPSLC_DIAG_FOLD (measurement switch, default on): update + factorisation of the diagonal tile in ONE
-                // launch (diag_update_potrf_kernel) instead of tile_syrk_diag_kernel followed by diag_potrf_inv_v2_kernel
+                // launch (diag_update_potrf_kernel) instead of tile_syrk_diag_kernel followed by diag_potrf_inv_la_kernel
                 static const int fold = diag_env("GPSLC_DIAG_FOLD", 1);
                 const bool fold_ok = fold && info_div == 1;
                 if (fold_ok) {

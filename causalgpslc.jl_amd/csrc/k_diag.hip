@@ -21,19 +21,19 @@
 
 #include "diag_block.h"
 
-__global__ __launch_bounds__(256, 2) void diag_potrf_inv_v2_kernel(TRef M, int k, double* inv,
+__global__ __launch_bounds__(256, 2) void diag_potrf_inv_la_kernel(TRef M, int k, double* inv,
                                                                     long long inv_bstride, int* info,
                                                                     int info_base) {
-    extern __shared__ __attribute__((aligned(16))) double P[];   // 36 blocks x 256 + Wcur[256]
+    extern __shared__ __attribute__((aligned(16))) double P[];   // 36 blocks x 256 + two W slots
     const long long b = blockIdx.x;
-    diag_potrf_inv_v2_body(P, tref_tile(M, b, k, k), inv + b * inv_bstride + (long long)k * GP_TSQ, info + b,
+    diag_potrf_inv_la_body(P, tref_tile(M, b, k, k), inv + b * inv_bstride + (long long)k * GP_TSQ, info + b,
                            info_base + GP_TS * k, (int)threadIdx.x, false);
 }
 
 void launch_diag(const TRef& M, int k, double* inv, long long inv_bstride, int* info,
                  int info_base, int nbatch, hipStream_t st) {
-    static DeviceOnce attr2;
-    lds_opt_in(attr2, (const void*)diag_potrf_inv_v2_kernel, DIAG2_LDS_BYTES);
-    hipLaunchKernelGGL(diag_potrf_inv_v2_kernel, dim3(nbatch), dim3(256), DIAG2_LDS_BYTES, st, M, k, inv,
+    static DeviceOnce attr3;
+    lds_opt_in(attr3, (const void*)diag_potrf_inv_la_kernel, DIAG3_LDS_BYTES);
+    hipLaunchKernelGGL(diag_potrf_inv_la_kernel, dim3(nbatch), dim3(256), DIAG3_LDS_BYTES, st, M, k, inv,
                        inv_bstride, info, info_base);
 }

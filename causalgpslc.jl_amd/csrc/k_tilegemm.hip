@@ -745,7 +745,7 @@ __device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, 
 // ---------------------------------------------------------------------------------------
 // Diagonal tile of an in-panel column in ONE launch (round 4): update of tile (k, k) over [k0, k1) with the
 // augmented rows riding along (what tile_syrk_diag_kernel<MT> does for it), then — on the packed image the update leaves in
-// LDS, without the HBM round trip of the tile — its Cholesky + inverse (what diag_potrf_inv_v2_kernel does).  One workgroup
+// LDS, without the HBM round trip of the tile — its Cholesky + inverse (what diag_potrf_inv_la_kernel does).  One workgroup
 // per matrix, two per CU.  This pairs the factorisation's fp64 pivot chains with the
 // diagonal update's sparse MFMA stream (9 MFMAs per wave and k-step between staging waits), not with a dense one.
 // ---------------------------------------------------------------------------------------
@@ -761,14 +761,14 @@ __global__ __launch_bounds__(256, 2) void diag_update_potrf_kernel(GemmArgs g) {
         case 2: syrk_chain_wave<2, MT>(g, b, td, g.k1, smem, tid, lane); break;
         default: syrk_chain_wave<3, MT>(g, b, td, g.k1, smem, tid, lane); break;
     }
-    diag_potrf_inv_v2_body(smem, tref_tile(g.C, b, td, td), tref_tile(g.F, b, 0, td), g.info + b, g.info_base + GP_TS * td,
+    diag_potrf_inv_la_body(smem, tref_tile(g.C, b, td, td), tref_tile(g.F, b, 0, td), g.info + b, g.info_base + GP_TS * td,
                            tid, true);
 }
 
 template <int MT>
 static void launch_diag_update_potrf_t(const GemmArgs& g, hipStream_t st) {
     static DeviceOnce once;
-    constexpr int bytes = DIAG2_LDS_BYTES > GEMM_LDS_BYTES ? DIAG2_LDS_BYTES : GEMM_LDS_BYTES;
+    constexpr int bytes = DIAG3_LDS_BYTES > GEMM_LDS_BYTES ? DIAG3_LDS_BYTES : GEMM_LDS_BYTES;
     lds_opt_in(once, (const void*)diag_update_potrf_kernel<MT>, bytes);
     hipLaunchKernelGGL(diag_update_potrf_kernel<MT>, dim3(g.nbatch), dim3(256), bytes, st, g);
 }

@@ -34,7 +34,7 @@ $KS $OUT/trace_c2 "rocprofv3 --kernel-trace --stats of the unit-A bench at BASEL
 $KS $OUT/trace_c2l "rocprofv3 --kernel-trace --stats of BASELINE config 2 as stated (N=1024 D=4 nU=1, ONE gpslc_predict_dev call with S = 1000 per step; 4 calls: 1 warm-up + 3 timed): kernel launches per call = calls / 4" 4000 > $OUT/kernel_stats_c2_literal.md
 { echo "## HBM traffic per kernel at BASELINE config 2 (N = 1024, D 4, nU 1; a launch = one chunk of 8,192 posterior samples)"; echo;
 i=0; mkdir -p $OUT/c2json
-for k in tile_fused_strip_kernel diag_update_potrf_kernel gram_kernel diag_potrf_inv_v2_kernel ite_mean_kernel backsolve_update_kernel "tile_gemm_nt_kernel<0, 0>" rhs_tiles_kernel backsolve_alpha_kernel rhs_prepare_kernel epilogue_kernel extract_z_kernel tile_syrk_diag_kernel "tile_gemm_nt_kernel<1, 0>"; do
+for k in tile_fused_strip_kernel diag_update_potrf_kernel gram_kernel diag_potrf_inv_la_kernel ite_mean_kernel backsolve_update_kernel "tile_gemm_nt_kernel<0, 0>" rhs_tiles_kernel backsolve_alpha_kernel rhs_prepare_kernel epilogue_kernel extract_z_kernel tile_syrk_diag_kernel "tile_gemm_nt_kernel<1, 0>"; do
   i=$((i+1)); echo "### $k"; $PS $OUT/c2pmc "$k" $OUT/c2json/k$i.json | tail -2; echo; done; } > $OUT/pmc_c2_per_kernel.md
 rm -rf $OUT/c2pmc $OUT/trace $OUT/trace_b $OUT/trace_c2 $OUT/trace_c2l
 head -22 $OUT/kernel_stats.md; head -8 $OUT/kernel_stats_c2_literal.md
