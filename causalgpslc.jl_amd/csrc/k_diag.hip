@@ -21,13 +21,25 @@
 
 #include "diag_block.h"
 
+#ifdef GPSLC_DIAG
+// measurement build: phase stamps of workgroup 0 of the last launch (tools/potrf_stamps.py reads them through the symbol below)
+__device__ unsigned long long g_potrf_stamps[2 * 40];
+extern "C" int gpslc_diag_potrf_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potrf_stamps), sizeof(unsigned long long) * 2 * 40);
+}
+#endif
 __global__ __launch_bounds__(256, 2) void diag_potrf_inv_la_kernel(TRef M, int k, double* inv,
                                                                     long long inv_bstride, int* info,
                                                                     int info_base) {
     extern __shared__ __attribute__((aligned(16))) double P[];   // 36 blocks x 256 + two W slots
     const long long b = blockIdx.x;
+#ifdef GPSLC_DIAG
+    unsigned long long* stamps = b == 0 ? g_potrf_stamps : nullptr;
+#else
+    unsigned long long* stamps = nullptr;
+#endif
     diag_potrf_inv_la_body(P, tref_tile(M, b, k, k), inv + b * inv_bstride + (long long)k * GP_TSQ, info + b,
-                           info_base + GP_TS * k, (int)threadIdx.x, false);
+                           info_base + GP_TS * k, (int)threadIdx.x, false, stamps);
 }
 
 void launch_diag(const TRef& M, int k, double* inv, long long inv_bstride, int* info,
