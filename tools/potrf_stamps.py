@@ -28,7 +28,7 @@ t0 = st[0].min()
 names = ["image loaded", "barrier", "block 0 factorised (wave 0)", "barrier"]
 for p in range(8):
     names += [f"step {p} phase 1 done", "barrier A", f"step {p} phase 2 done", "barrier B"]
-print(f"N={n}, {S} matrices per launch; clocks since the first stamp (s_memtime, 100 MHz x ... shader clock domain): wave 0 / wave 1")
+print(f"N={n}, {S} matrices per launch; shader clocks (s_memtime) since the first stamp: wave 0 / wave 1 of workgroup 0 (the first workgroup of its CU: its first block and first step also pay the instruction-cache misses)")
 for i, nm in enumerate(names[:36]):
     print(f"{nm:34s} {st[i, 0] - t0:9d} {st[i, 1] - t0:9d}")
 print("total", (st[35].max() - t0))
