@@ -15,11 +15,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define NSB (GP_TS / SB)
 
-__device__ __forceinline__ double readlane_f64(double x, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
-    return __hiloint2double(hi, lo);
-}
 // acc[v] <-> (row = lane&15 of the `rowside` operand's row index, col = (lane>>4)+4v of `colside`'s)
 __device__ __forceinline__ d4 mma(double colside, double rowside, d4 acc) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(colside, rowside, acc, 0, 0, 0);
@@ -31,14 +26,14 @@ __device__ __forceinline__ d4 mma_neg(double colside, double rowside, d4 acc) {
 // The arithmetic runs on a PACKED image — only the 36 lower 16 x 16 sub-blocks live in LDS
 // (72 KiB + 2 KiB slots for inv(L_pp)), so TWO workgroups fit a CU.  The kernel is latency
 // bound (one 8-step dependency chain per matrix), so residency is throughput: 352 -> ~190 us per 1024
-// matrices.  What makes the packing possible:
+// matrices (round 2; round 5: ~120 us).  What makes the packing possible:
 //   * block row p of L is final after step p: it is written to the output tile right away and its LDS slots
 //     are then overwritten, in place, by block row p of inv(L):
 //         W_pq = -W_pp * sum_{m=q}^{p-1} L_pm W_mq        (q < p; needs rows < p of W only),
 //     i.e. the inversion runs row-wise inside the factorisation loop instead of column-wise after it;
 //   * W blocks are stored transposed (element (r, c) at r*16 + c) so that they are read as MFMA operands with
 //     the conflict-free fragment pattern; slot (p, p) receives W_pp^T once L_pp has been written out.
-// Summation orders are those of version 1 (same MFMA chains).
+// Summation orders of the block products are those of versions 1 and 2 (same MFMA chains).
 // ---------------------------------------------------------------------------------------
 #define BLK(i, j) (P + ((((i) * ((i) + 1)) / 2 + (j)) << 8))
 // fragment of a packed 16 x 16 block (column-major, ld 16): element (row = lane&15, k = 4kk + lane>>4)
@@ -52,10 +47,10 @@ __device__ __forceinline__ double bfrag(const double* blk, int kk, int lane) {
 // (b) panel X_i = A_i W_pp^T, (b') block row p of inv(L), the output rows, (c) trailing update A_ij -= X_i X_j^T.  Until round 4
 // (a) ran while the other three waves waited at a barrier and (b), (c) while that wave had nothing to do.  Now wave 0 is taken
 // off the block updates: in step p it computes the panel block
-// (p+1, p), applies it to the diagonal block (p+1, p+1) — the only update of step p that block needs — and factorises it
-// (Cholesky before the mid-step barrier, inverse after it) into the SECOND W slot, while waves 1..3 do everything else of
-// step p: the remaining panel blocks, block row p of inv(L), the output rows, the trailing blocks.  Step p + 1 then starts
-// with its diagonal block already factorised.  Arithmetic: every block receives the same MFMA chains in the same order as
+// (p+1, p), applies it to the diagonal block (p+1, p+1) — the only update of step p that block needs — and factorises +
+// inverts it (one sweep: sb_factor_inv) into the SECOND W slot, all in phase 1, while waves 1..3 do the rest of phase 1: the
+// remaining panel blocks, block row p of inv(L), the output rows.  The trailing blocks of phase 2 are dealt to all four waves.
+// Step p + 1 then starts with its diagonal block already factorised.  Arithmetic: every block receives the same MFMA chains in the same order as
 // the loop without lookahead; the 16 x 16 factor and its inverse come from sb_factor_inv below (same algorithm class, different
 // rounding in the last bits than rounds 1-4).  LDS: one more 2 KiB W slot and a 128-byte broadcast line.
 // ---------------------------------------------------------------------------------------
