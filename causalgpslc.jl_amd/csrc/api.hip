@@ -260,7 +260,7 @@ void gemm(gpslc_ctx* c, const GemmArgs& g0, hipStream_t st, int prof_base = 0) {
     if (use_queue)
         for (size_t i = 0; i < c->streams.size() && i < c->queues.size(); ++i)
             if (c->streams[i] == st) g.queue = c->queues[i];
-    if (g.ntiles <= 0 || g.nbatch <= 0 || (g.k1 <= g.k0 && g.accumulate)) return;
+    if (g.ntiles <= 0 || g.nbatch <= 0 || (g.k1 <= g.k0 && g.accumulate && !g.fuse)) return;     // fuse with an empty K range: panel product only
 #ifdef GPSLC_DIAG
     // measurement build only: timing-only kernel variants (results are garbage by construction) and in-kernel
     // stamps of one trailing update, written to gpurun_out/gemm_dbg.bin
@@ -461,11 +461,21 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
         }
         if (!fused) launch_diag(M, k, inv, inv_bstride, info, info_base, nb, st);
         if (!fused && ntot - k - 1 > 0) {   // panel: tile(i,k) = tile(i,k) * inv(L_kk)^T
+            // GPSLC_PANEL0_STRIP (measurement switch, default on, round 5): the first column of a panel has no column update — its
+            // panel product runs as the strip kernel's second phase alone (empty K range: the tile goes from HBM into the
+            // accumulators, the fragments of inv(L_kk) from L2 into registers, no LDS staging), same summation order as the
+            // general product it replaces (tile_gemm_nt_kernel<0, 0>)
+            static const int p0strip = diag_env("GPSLC_PANEL0_STRIP", 1);
             GemmArgs g{};
-            g.A = M; g.B = invref; g.C = M;
+            g.A = M; g.C = M;
             g.shape = 1; g.i0 = k + 1; g.j0 = k; g.mi = ntot - k - 1; g.mj = 1;
-            g.k0 = k; g.k1 = k + 1; g.accumulate = 0; g.nbatch = nb; g.ntiles = g.mi;
+            g.nbatch = nb; g.ntiles = g.mi;
             g.short_row0 = nt; g.short_rows = short_rows;
+            if (p0strip && fuse_mode()) {
+                g.B = M; g.k0 = k; g.k1 = k; g.accumulate = 1; g.fuse = 1; g.F = invref; g.fk = k;
+            } else {
+                g.B = invref; g.k0 = k; g.k1 = k + 1; g.accumulate = 0;
+            }
             gemm(c, g, st, prof_base);
         }
         // skip_aug_diag (single short augmented row, epilogue sums from the rows of R): the augmented diagonal tile is
@@ -745,7 +755,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                         g.shape = 1; g.i0 = 0; g.j0 = k; g.mi = nt; g.mj = 1; g.nbatch = ub; g.ntiles = nt;
                         // fused up to a K depth of w_fuse_maxk tiles (measurement switch; +0.7 % fused at every depth)
                         static const int w_fuse_maxk = diag_env("GPSLC_FUSE_W_MAXK", 32);
-                        if (k > ka && k - ka <= w_fuse_maxk && fuse_mode()) {
+                        if (k - ka <= w_fuse_maxk && fuse_mode()) {      // k == ka: empty K range, the panel product alone (round 5)
                             g.B = Ls; g.k0 = ka; g.k1 = k; g.accumulate = 1;
                             g.fuse = 1; g.F = invref; g.fk = k;
                             gemm(c, g, st, 3);
