@@ -587,8 +587,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
     // L > Bb levels — sized below through the extra term)
     // spp <= 128: the streaming draw kernel reads the unit's normals (caller's or Philox) from an operand image of
     // 16 Np doubles per block of 16 draws (DrawArgs::zt) instead
-    static const int draws_stream = diag_env("GPSLC_DRAWS_STREAM", 1);      // measurement switch: 0 = the LDS-staged kernel of rounds 2-4
-    const bool zimage = want_draws && io.spp <= 128 && draws_stream;
+    const bool zimage = want_draws && io.spp <= 128;
     // per unit: 1 / 2 / 4 / 8 blocks of 16 draws (draws_nq, k_solve.hip: the stream kernel's template parameter)
     const size_t zimage_doubles = zimage ? (size_t)16 * (io.spp <= 16 ? 1 : io.spp <= 32 ? 2 : io.spp <= 64 ? 4 : 8) * Np : 0;
     const size_t draws_per = want_draws ? ((zimage ? zimage_doubles * 8 + 256 : (io.z ? 0 : (size_t)io.spp * n * 8 + 256)) +

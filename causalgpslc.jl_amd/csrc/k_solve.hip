@@ -589,110 +589,40 @@ __global__ __launch_bounds__(256) void draws_mfma_kernel(DrawArgs a) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) acc[m][q] = (d4s){0.0, 0.0, 0.0, 0.0};
-#ifdef DRAWS_NO_PIPE      // A/B knob (variant build): the un-pipelined chunk loop for every NQ
-        if constexpr (false) {
-#else
-        if constexpr (NQ == 1) {
-#endif
-            // Chunks of 64 columns of the tile row, software-pipelined (round 4): the 16 loads of chunk c + 1 are in flight
-            // while chunk c runs its staging barriers and MFMAs.  Two things make that real: the z loads of a chunk are issued
-            // BEFORE the factor loads of the next one (vmcnt counts in order: waiting for a younger load would wait for the
-            // prefetch as well), and the two barriers order LDS traffic only (__syncthreads() waits vmcnt(0): every load in
-            // flight).  Same chunk order and MFMA chains as before: bit-identical draws.
-            constexpr int ZPT = DR_KC * ND / 256;               // z values a thread stages per chunk
-            const int nchunk = (ib + 1) * (GP_TS / DR_KC);
-            auto load_l = [&](int c, d2s (&lv)[DR_KC / 4]) {
-                const double* __restrict__ t = tref_tile(a.Lc, b, ib, c / (GP_TS / DR_KC)) + r0;
-                const int kc = c % (GP_TS / DR_KC);
+        // (rounds 2-4 ran 1..128 draws through this kernel, with a software-pipelined form for <= 16: since round 5 it serves units of
+        // more than 128 draws only — several passes over L_c; profiles/r05_draws_lds_kernel.patch has the removed branches)
+        for (int jt = 0; jt <= ib; ++jt) {
+            const double* __restrict__ t = tref_tile(a.Lc, b, ib, jt) + r0;
+#pragma unroll 1
+            for (int kc = 0; kc < GP_TS / DR_KC; ++kc) {
+                // this lane's rows of the 16 column groups of the chunk: 16 independent 16-byte loads in flight
+                d2s lv[DR_KC / 4];
 #pragma unroll
                 for (int kk = 0; kk < DR_KC / 4; ++kk)
                     lv[kk] = *reinterpret_cast<const d2s*>(t + (kc * DR_KC + 4 * kk + lq) * GP_TS);
-            };
-            auto load_z = [&](int c, double (&zr)[ZPT]) {
-                const int jt = c / (GP_TS / DR_KC), kc = c % (GP_TS / DR_KC);
-    #pragma unroll
-                for (int u = 0; u < ZPT; ++u) {
-                    const int idx = tid + 256 * u;
+                __syncthreads();
+                for (int idx = tid; idx < DR_KC * ND; idx += 256) {
                     const int k = idx & (DR_KC - 1), dd = idx / DR_KC;
                     const long long g = (long long)jt * GP_TS + kc * DR_KC + k;
-                    zr[u] = (dd < nd && g < n) ? zu[g + n * (d0 + dd)] : 0.0;
+                    zs[k * ZLD + dd] = (dd < nd && g < n) ? zu[g + n * (d0 + dd)] : 0.0;
                 }
-            };
-            auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-            auto run_chunk = [&](int c, d2s (&lv)[DR_KC / 4], const double (&zr)[ZPT]) {
-                const int jt = c / (GP_TS / DR_KC), kc = c % (GP_TS / DR_KC);
-                lds_barrier();                                   // the previous chunk's readers are done with zs
-    #pragma unroll
-                for (int u = 0; u < ZPT; ++u) {
-                    const int idx = tid + 256 * u;
-                    zs[(idx & (DR_KC - 1)) * ZLD + idx / DR_KC] = zr[u];
-                }
-                lds_barrier();
+                __syncthreads();
                 if (jt == ib) {     // diagonal tile: only the lower triangle belongs to L_c
-    #pragma unroll
+#pragma unroll
                     for (int kk = 0; kk < DR_KC / 4; ++kk) {
-                        const int cc = kc * DR_KC + 4 * kk + lq;
-                        if (cc > r0) lv[kk].x = 0.0;
-                        if (cc > r0 + 1) lv[kk].y = 0.0;
+                        const int c = kc * DR_KC + 4 * kk + lq;
+                        if (c > r0) lv[kk].x = 0.0;
+                        if (c > r0 + 1) lv[kk].y = 0.0;
                     }
                 }
-    #pragma unroll
+#pragma unroll
                 for (int kk = 0; kk < DR_KC / 4; ++kk) {
-                    const double* zrow = zs + (4 * kk + lq) * ZLD + li;
-    #pragma unroll
+                    const double* zr = zs + (4 * kk + lq) * ZLD + li;
+#pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        const double zf = zrow[16 * q];
+                        const double zf = zr[16 * q];
                         acc[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, lv[kk].x, acc[0][q], 0, 0, 0);
                         acc[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, lv[kk].y, acc[1][q], 0, 0, 0);
-                    }
-                }
-            };
-            d2s lvA[DR_KC / 4], lvB[DR_KC / 4];
-            double zA[ZPT], zB[ZPT];
-            load_z(0, zA);
-            load_l(0, lvA);
-            for (int c = 0; c < nchunk; c += 2) {        // nchunk is even (two chunks per tile)
-                load_z(c + 1, zB);
-                load_l(c + 1, lvB);
-                run_chunk(c, lvA, zA);
-                if (c + 2 < nchunk) { load_z(c + 2, zA); load_l(c + 2, lvA); }
-                run_chunk(c + 1, lvB, zB);
-            }
-            lds_barrier();                                   // before the next pass of draws (d0) restages zs
-        } else {     // spp > 16: two staging sets of 16 loads no longer fit the register file at two waves per SIMD, and beyond 32 draws the pass is MFMA-bound anyway
-            for (int jt = 0; jt <= ib; ++jt) {
-                const double* __restrict__ t = tref_tile(a.Lc, b, ib, jt) + r0;
-    #pragma unroll 1
-                for (int kc = 0; kc < GP_TS / DR_KC; ++kc) {
-                    // this lane's rows of the 16 column groups of the chunk: 16 independent 16-byte loads in flight
-                    d2s lv[DR_KC / 4];
-    #pragma unroll
-                    for (int kk = 0; kk < DR_KC / 4; ++kk)
-                        lv[kk] = *reinterpret_cast<const d2s*>(t + (kc * DR_KC + 4 * kk + lq) * GP_TS);
-                    __syncthreads();
-                    for (int idx = tid; idx < DR_KC * ND; idx += 256) {
-                        const int k = idx & (DR_KC - 1), dd = idx / DR_KC;
-                        const long long g = (long long)jt * GP_TS + kc * DR_KC + k;
-                        zs[k * ZLD + dd] = (dd < nd && g < n) ? zu[g + n * (d0 + dd)] : 0.0;
-                    }
-                    __syncthreads();
-                    if (jt == ib) {     // diagonal tile: only the lower triangle belongs to L_c
-    #pragma unroll
-                        for (int kk = 0; kk < DR_KC / 4; ++kk) {
-                            const int c = kc * DR_KC + 4 * kk + lq;
-                            if (c > r0) lv[kk].x = 0.0;
-                            if (c > r0 + 1) lv[kk].y = 0.0;
-                        }
-                    }
-    #pragma unroll
-                    for (int kk = 0; kk < DR_KC / 4; ++kk) {
-                        const double* zr = zs + (4 * kk + lq) * ZLD + li;
-    #pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            const double zf = zr[16 * q];
-                            acc[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, lv[kk].x, acc[0][q], 0, 0, 0);
-                            acc[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf, lv[kk].y, acc[1][q], 0, 0, 0);
-                        }
                     }
                 }
             }
@@ -955,29 +885,8 @@ void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st) {
         if (a.spp > 64) { hipLaunchKernelGGL((draws_stream_kernel<16, 2, 1, 8>), grid, dim3(256), 0, st, a); return; }
         if (a.spp > 32) { hipLaunchKernelGGL((draws_stream_kernel<16, 3, 2, 4>), grid, dim3(256), 0, st, a); return; }
         if (a.spp > 16) { hipLaunchKernelGGL((draws_stream_kernel<16, 3, 3, 2>), grid, dim3(256), 0, st, a); return; }
-#ifdef GPSLC_DIAG
-        // measurement build: GPSLC_DRAWS_VAR picks the register-set arrangement, GPSLC_DRAWS_LDS pads the workgroup's LDS
-        // allocation (KiB) to pin the number of workgroups per CU
-        static const int var = diag_env("GPSLC_DRAWS_VAR", 0);
-        static const int pad = diag_env("GPSLC_DRAWS_LDS", 0) * 1024;
-        auto go = [&](auto kern) {
-            if (pad > 0) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-            hipLaunchKernelGGL(kern, grid, dim3(256), pad, st, a);
-        };
-        // round 5, one box (profiles/r05_ab_experiments.md §1), TB/s of factor stream at N = 4096, 64 units x 10 draws:
-        //   <32,2,2> 5.62-5.65   <32,2,3> 5.59   <32,3,2> 5.55   <16,4,3> 5.60   <16,4,4> 6.02   <16,3,4> 6.04 (production)
-        if (var == 2) { go(draws_stream_kernel<16, 4, 4>); return; }
-        if (var == 3) { go(draws_stream_kernel<32, 2, 3>); return; }
-        if (var == 4) { go(draws_stream_kernel<16, 4, 3>); return; }
-        if (var == 5) { go(draws_stream_kernel<32, 3, 2>); return; }
-        if (var == 6) { go(draws_stream_kernel<32, 2, 2>); return; }
-        if (var == 7) { go(draws_stream_kernel<8, 4, 4>); return; }
-        if (var == 8) { go(draws_stream_kernel<8, 6, 4>); return; }
-        if (var == 9) { go(draws_stream_kernel<16, 2, 4>); return; }
-        if (var == 10) { go(draws_stream_kernel<16, 3, 5>); return; }
-        if (var == 11) { go(draws_stream_kernel<8, 4, 6>); return; }
-        if (var != 0 || pad > 0) { go(draws_stream_kernel<16, 3, 4>); return; }
-#endif
+        // register-set arrangements tried (profiles/r05_ab_experiments.md §1): <32,2,2> 5.62-5.65 TB/s, <32,2,3> 5.59, <32,3,2> 5.55,
+        // <16,4,3> 5.60, <16,4,4> 6.02, <16,3,4> 6.04 (this one) on one box; 5.5-5.6 for every one of them on another
         hipLaunchKernelGGL((draws_stream_kernel<16, 3, 4>), grid, dim3(256), 0, st, a);
         return;
     }
@@ -986,10 +895,7 @@ void launch_draws(const DrawArgs& a, int nbatch, hipStream_t st) {
         hipLaunchKernelGGL(normals_kernel, dim3((unsigned)((pairs + 255) / 256), nbatch), dim3(256), 0, st, a.seed, a.rs0,
                            a.rS, a.l, a.lc, (long long)a.n, a.spp, a.zgen);
     }
-    if (a.spp <= 16) launch_draws_t<1>(a, nbatch, st);
-    else if (a.spp <= 32) launch_draws_t<2>(a, nbatch, st);
-    else if (a.spp <= 64) launch_draws_t<4>(a, nbatch, st);
-    else launch_draws_t<8>(a, nbatch, st);
+    launch_draws_t<8>(a, nbatch, st);      // more than 128 draws per unit: passes of 128
 }
 void launch_draws_scatter(const double* tmp, double* out, long long n, int L, int spp, long long s0, int nbatch,
                           hipStream_t st) {
