@@ -381,6 +381,7 @@ static void launch_ite_mean_r(const IteMeanArgs& a, int nbatch, hipStream_t st) 
     // exact register counts for the common feature widths: the pass is fp64-VALU bound (2 instructions per
     // feature per element), a padded feature is paid in full
     if (F <= 4) launch_ite_mean_f<4, RT>(a, nbatch, st);
+    else if (F <= 5) launch_ite_mean_f<5, RT>(a, nbatch, st);      // BASELINE config 2: nU + nX = 1 + 4
     else if (F <= 6) launch_ite_mean_f<6, RT>(a, nbatch, st);
     else if (F <= 8) launch_ite_mean_f<8, RT>(a, nbatch, st);
     else if (F <= 10) launch_ite_mean_f<10, RT>(a, nbatch, st);
