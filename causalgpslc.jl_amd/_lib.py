@@ -69,6 +69,7 @@ SIGNATURES = {
                                     C.c_int32, C.c_uint64, _D, _D, _D, _D, _D]),
     "gpslc_predict_multi": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.c_int64, _D, _D, _D, _D, _D, _D, C.c_int32, _D,
                                       C.c_double, C.c_int32, C.c_uint64, _D, _D, _D, _D, _D, c_int32_p]),
+    "gpslc_shard_range": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, c_int64_p, c_int64_p]),
     "gpslc_ite_distributions": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D, _D, _D, C.c_double,
                                           C.c_double, _D, _D]),
     "gpslc_likelihood_distribution": (C.c_int, [C.c_void_p, _D, _D, _D, C.c_double, C.c_double, C.c_double,

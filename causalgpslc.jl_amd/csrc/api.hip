@@ -1352,6 +1352,18 @@ int gpslc_predict(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, 
     });
 }
 
+int gpslc_shard_range(int64_t S, int32_t nblocks, int32_t k, int64_t* s0, int64_t* s1) {
+    if (S < 0) return -1;
+    if (nblocks < 1) return -2;
+    if (k < 0 || k >= nblocks) return -3;
+    if (!s0) return -4;
+    if (!s1) return -5;
+    const int64_t q = S / nblocks, r = S % nblocks;
+    *s0 = k * q + std::min<int64_t>(k, r);
+    *s1 = *s0 + q + (k < r ? 1 : 0);
+    return GPSLC_OK;
+}
+
 // The sharded ensemble behind the ABI (the loop src/prediction.jl:30-33 over src/estimation.jl:78-84): contiguous
 // blocks of the posterior-sample index over the contexts, one host thread per context, data replicated (every ctx holds its own
 // copy: gpslc_set_data), no traffic between the devices while they compute.  The "gather" is each device's own device-to-host
@@ -1389,10 +1401,10 @@ int gpslc_predict_multi(int32_t nctx, gpslc_ctx* const* ctxs, int64_t S, const d
         std::vector<Shard> sh((size_t)nctx);
         const bool use_z = z && ite_draws;
         for (int k = 0; k < nctx; ++k) {
-            const int64_t q = S / nctx, r = S % nctx;
             Shard& h = sh[(size_t)k];
-            h.s0 = k * q + std::min<int64_t>(k, r);
-            h.Sr = q + (k < r ? 1 : 0);
+            int64_t s1 = 0;
+            (void)gpslc_shard_range(S, nctx, k, &h.s0, &s1);
+            h.Sr = s1 - h.s0;
             if (h.Sr == 0 || L == 1) continue;
             if (use_z) {
                 h.z.resize((size_t)(n * spp * h.Sr * L));

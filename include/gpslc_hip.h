@@ -215,6 +215,12 @@ int gpslc_predict_multi(int32_t nctx, gpslc_ctx* const* ctxs, int64_t S, const d
                         const double* z_or_null, double* meanSATE, double* varSATE, double* meanITE,
                         double* ite_draws, int32_t* info_or_null);
 
+/* The partition gpslc_predict_multi uses, for callers who drive the contexts themselves (results LEFT on their devices:
+ * gpslc_predict_dev per context after gpslc_set_ensemble(ctx_k, s0, S)): block k of nblocks is the posterior samples [*s0, *s1),
+ * sizes differ by at most one, the first S mod nblocks blocks are the longer ones.  Host-only arithmetic (no ctx, no GPU); the
+ * same partition as causalgpslc.jl_amd/sharded.py: shard_range. */
+int gpslc_shard_range(int64_t S, int32_t nblocks, int32_t k, int64_t* s0, int64_t* s1);
+
 /* ITEDistributions(g, doT) (src/estimation.jl:66-86) for one intervention level, with the
  * reference's output layout: MeanITEs S x n and CovITEs S x n x n, sample index fastest;
  * CovITEs carries the + pred_noise*I of src/estimation.jl:82.  Either output may be NULL. */

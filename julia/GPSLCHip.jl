@@ -257,6 +257,16 @@ function predict_multi(cs::Vector{Ctx}, p::Pack, doT::Vector{Float64}, pred_nois
     mS, vS, mI, dr, info
 end
 
+"""shard_range(S, nblocks, k): the 0-based half-open block [s0, s1) of posterior samples `predict_multi` gives context k
+(k = 0 … nblocks − 1) — for callers who leave every block's results on its own device (`predict_dev` per context after
+`set_ensemble!(ctx_k, s0, S)`)."""
+function shard_range(S::Integer, nblocks::Integer, k::Integer)
+    s0, s1 = Ref{Int64}(0), Ref{Int64}(0)
+    st = ccall((:gpslc_shard_range, lib), Cint, (Int64, Int32, Int32, Ref{Int64}, Ref{Int64}), S, nblocks, k, s0, s1)
+    st == 0 || error("gpslc_shard_range: status $st")
+    s0[], s1[]
+end
+
 """As `predict`, every array argument a DEVICE pointer (ROCArray memory); outputs stay in HBM."""
 predict_dev(c::Ctx, S::Integer, U::Ptr{Float64}, uyLS::Ptr{Float64}, xyLS::Ptr{Float64}, tyLS::Ptr{Float64},
             yScale::Ptr{Float64}, yNoise::Ptr{Float64}, L::Integer, doT::Ptr{Float64}, pred_noise::Float64,

@@ -45,6 +45,28 @@ def test_host_only_entry_point_sate_samples():
     assert np.allclose(out, ref, rtol=0, atol=1e-15)
 
 
+def test_shard_range_is_the_python_drivers_partition():
+    """gpslc_shard_range (host-only): the partition gpslc_predict_multi uses = causalgpslc.jl_amd/sharded.py: shard_range, for
+    every (S, nblocks) a node would see; blocks are contiguous, ordered, cover [0, S) and differ in size by at most one."""
+    import ctypes as C
+    from causalgpslc_jl_amd.sharded import shard_range
+    lib = _lib.load()
+    s0, s1 = C.c_int64(), C.c_int64()
+    for S in (0, 1, 2, 5, 7, 8, 64, 1000, 8191, 8192):
+        for nb in (1, 2, 3, 4, 7, 8):
+            end = 0
+            for k in range(nb):
+                assert lib.gpslc_shard_range(S, nb, k, C.byref(s0), C.byref(s1)) == 0
+                assert (s0.value, s1.value) == shard_range(S, nb, k)
+                assert s0.value == end and 0 <= s1.value - s0.value - S // nb <= 1
+                end = s1.value
+            assert end == S
+    assert lib.gpslc_shard_range(-1, 2, 0, C.byref(s0), C.byref(s1)) == -1
+    assert lib.gpslc_shard_range(4, 0, 0, C.byref(s0), C.byref(s1)) == -2
+    assert lib.gpslc_shard_range(4, 2, 2, C.byref(s0), C.byref(s1)) == -3
+    assert lib.gpslc_shard_range(4, 2, 0, None, C.byref(s1)) == -4
+
+
 def test_argument_validation_mirrors_reference_asserts():
     import numpy as np
     with pytest.raises(AssertionError):   # src/kernel.jl:25 "X1 and X2 are different sizes!"
