@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--panel", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)
+    ap.add_argument("--task-tiles", type=int, default=-1,
+                    help="gpslc_set_task_schedule: matrices of up to this many tiles per side take the persistent "
+                         "factorisation launch (0 = one launch per tile column, -1 = the library's default)")
+    ap.add_argument("--task-group", type=int, default=0, help="gpslc_set_task_schedule: matrices per group of the task order")
     ap.add_argument("--no-mean-ite", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-units", type=int, default=3)
@@ -391,7 +395,7 @@ def run_config(gp, synth, np, torch, dev, local_rank, n, D, K, S, L, binary_t, f
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof = [ctx.profile_get(k) for k in (0, 1)]
+    prof = [ctx.profile_get(k) for k in (0, 1, 4)]
     ctx.close()
     flop = float(n) ** 3 / 3.0 + float(n) ** 2 * (3 * (D + K + 1) + 4 + 5 * L)
     val = S * steps / dt
@@ -412,7 +416,7 @@ def run_config(gp, synth, np, torch, dev, local_rank, n, D, K, S, L, binary_t, f
                           "ceiling_units_per_s": HBM_PEAK_GBPS * 1e9 / bps,
                           "note": "HBM bytes per sample from the PMC passes (" + bnote + ") x samples/s; frac_of_ceiling above "
                                   "is against the MFMA peak"}
-    names = ("trailing_update_kernel", "fused_in_panel_kernel")
+    names = ("trailing_update_kernel", "fused_in_panel_kernel", "task_kernel")
     for nm, (ln, ms, fl) in zip(names, prof):
         if ln > 0 and ms > 0:
             rec[nm] = {"achieved": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
@@ -600,6 +604,7 @@ def main():
     ctx = gp.Context(n, D, K, device=local_rank, profile=not a.no_profile, fp32_kernel=a.fp32_kernel)
     ctx.check(ctx.lib.gpslc_set_data_dev(ctx.h, ptr(dX), ptr(dT), ptr(dY)))
     ctx.set_tuning(a.max_batch, a.panel, a.streams)
+    ctx.set_task_schedule(a.task_tiles, a.task_group)
 
     gathered_m = [torch.empty_like(mS) for _ in range(world)] if use_dist else None
     gathered_v = [torch.empty_like(vS) for _ in range(world)] if use_dist else None
@@ -639,6 +644,7 @@ def main():
         dt = float(tt.item())
     launches, kms, kflop = ctx.profile_get(0)      # tile_gemm_nt_kernel<1, 0>: the dominant kernel
     launches1, kms1, kflop1 = ctx.profile_get(1)   # tile_fused_strip_kernel: in-panel column update fused with the panel solve
+    ctx_prof4 = ctx.profile_get(4)                 # potrf_tasks_kernel: the persistent factorisation launch (N <= 1024)
     # the spread of the measurement: the same K steps timed again (--repeats - 1 more regions, bracketed like the first).  `value`
     # stays the FIRST region (exactly K steps after W warm-up steps, as the contract says); value_runs lists all of them.
     region_s = [dt]
@@ -753,6 +759,14 @@ def main():
         # small N (at most one panel of tile columns): the in-panel instantiation is the dominant kernel
         launches, kms, kflop, launches1, kms1, kflop1 = launches1, kms1, kflop1, launches, kms, kflop
         kname, kname1 = kname1, kname
+    launches4, kms4, kflop4 = ctx_prof4
+    if kms4 > kms:
+        # N <= 1024 with the default schedule: the whole factorisation is ONE persistent launch of tile tasks
+        launches1, kms1, kflop1 = launches, kms, kflop
+        kname1 = kname
+        launches, kms, kflop = launches4, kms4, kflop4
+        kname = ("potrf_tasks_kernel (f64 MFMA tile tasks: the whole left-looking factorisation of a chunk in one persistent "
+                 "launch; flop = n^3/3 + right-hand sides x n^2 per matrix)")
 
     rc = 0
     if rank == 0:

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -98,7 +99,16 @@ struct ProfRec {
     double flop;
     int cls;     // kernel class, see gpslc_profile_get_class (include/gpslc_hip.h)
 };
-constexpr int kProfClasses = 4;
+constexpr int kProfClasses = 5;
+
+// device-resident task list of one (tile count, augmented row, batch size, group size) shape of the persistent
+// factorisation launch (potrf_tasks_kernel); built once per shape and kept (see task_list_for)
+struct TaskList {
+    int nt = 0, aug = 0, nb = 0, G = 0;
+    unsigned* dev = nullptr;
+    long long ntasks = 0;
+    unsigned long long used = 0;
+};
 
 }  // namespace
 
@@ -118,6 +128,15 @@ struct gpslc_ctx {
     std::vector<hipStream_t> streams;
     std::vector<Arena> arenas;     // one per stream slot
     std::vector<int*> queues;      // one ticket-counter block (16 ints) per stream slot, see GemmArgs::queue
+    // persistent factorisation launch (potrf_tasks_kernel): progress words per stream slot, cached task lists, and whether
+    // a call has used it (its time-out word is then checked when the call's streams have drained)
+    std::vector<int*> task_sync;
+    std::vector<size_t> task_sync_ints;
+    std::vector<TaskList> task_lists;
+    unsigned long long task_clock = 0;
+    bool task_used = false;
+    int task_max_nt = 8;           // tile counts up to this one take the persistent launch (N <= 1024)
+    int task_group = 8;            // matrices per group of the task order (see build_task_list)
     Arena scratch;                 // call-level buffers (internal MeanITE of a draws-only call, ...)
     PoolArena io;                  // staging of the host-pointer entry points and per-call info words
     // single-launch small-n node scores (k_small.hip): pinned, device-visible host staging (descriptors, inputs,
@@ -382,13 +401,149 @@ const unsigned short* tri_order(gpslc_ctx* c, int m) {
 TRef lower_ref(double* base, long long bstride) { return TRef{base, bstride, 0, 0, 0, 0}; }
 TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstride, 1, 0, 0, ld}; }
 
+// ---- the persistent factorisation launch (potrf_tasks_kernel, k_tilegemm.hip) -------------------------------------------
+// Task order of one queue (= one XCD's contiguous run of matrices).  Stages of a matrix: s = 2k: diag(k), s = 2k + 1: the
+// strips of column k.  Matrices are taken in groups of G; step t of the order holds stage s of group t - s for every s — a
+// skewed wavefront, so that (1) every task follows its producers (stage s - 1 of the same group sits one whole step
+// earlier: ~ G * (nt + nt (nt + 1) / 2) tickets, several rounds of the XCD's 64 workgroup slots — a consumer practically
+// never finds its producer unfinished), and (2) every stretch of the order mixes the latency-bound diagonal tasks of some
+// groups with the MFMA-bound strips of others.  Inside a stage the strips of one matrix are consecutive tickets: they run
+// at the same time on one XCD and share the B panel L(k, 0..k-1) in its L2.  The strip of tile row k + 1 and the augmented
+// row come first (the next diagonal task waits for exactly those two).
+std::vector<unsigned> build_task_list(int nt, int aug, int nb, int G, long long* ntasks_out) {
+    std::vector<unsigned> out(TASK_LIST_HDR, 0u);
+    const int NS = 2 * nt;
+    long long total = 0;
+    const int wq = nb >> 3, wrm = nb & 7;
+    for (int x = 0; x < 8; ++x) {
+        const int x0 = x * wq + std::min(x, wrm), xc = wq + (x < wrm ? 1 : 0);
+        const size_t first = out.size() - TASK_LIST_HDR;
+        const int NG = (xc + G - 1) / G;
+        for (int t = 0; t < NG + NS - 1; ++t)
+            for (int s = 0; s < NS; ++s) {
+                const int g = t - s;
+                if (g < 0 || g >= NG) continue;
+                const int k = s >> 1;
+                for (int j = g * G; j < std::min(xc, (g + 1) * G); ++j) {
+                    const int b = x0 + j;
+                    if ((s & 1) == 0) { out.push_back(task_pack(b, k, k, 1)); continue; }
+                    if (k + 1 < nt) out.push_back(task_pack(b, k, k + 1, 0));
+                    if (aug) out.push_back(task_pack(b, k, nt, 0));
+                    for (int i = k + 2; i < nt; ++i) out.push_back(task_pack(b, k, i, 0));
+                }
+            }
+        out[x] = (unsigned)first;
+        out[8 + x] = (unsigned)(out.size() - TASK_LIST_HDR - first);
+        total += out[8 + x];
+    }
+    *ntasks_out = total;
+    return out;
+}
+
+const TaskList& task_list_for(gpslc_ctx* c, int nt, int aug, int nb, int G) {
+    for (auto& t : c->task_lists)
+        if (t.nt == nt && t.aug == aug && t.nb == nb && t.G == G) { t.used = ++c->task_clock; return t; }
+    if (c->task_lists.size() >= 8) {       // evict the least recently used shape (nothing of it may still be in flight)
+        size_t v = 0;
+        for (size_t i = 1; i < c->task_lists.size(); ++i)
+            if (c->task_lists[i].used < c->task_lists[v].used) v = i;
+        HC(hipDeviceSynchronize());
+        HC(hipFree(c->task_lists[v].dev));
+        c->task_lists.erase(c->task_lists.begin() + (long)v);
+    }
+    TaskList t;
+    t.nt = nt; t.aug = aug; t.nb = nb; t.G = G;
+    std::vector<unsigned> h = build_task_list(nt, aug, nb, G, &t.ntasks);
+    HC(hipMalloc((void**)&t.dev, h.size() * sizeof(unsigned)));
+    HC(hipMemcpy(t.dev, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    t.used = ++c->task_clock;
+    c->task_lists.push_back(t);
+    return c->task_lists.back();
+}
+
+// the persistent launch serves: one left-looking panel over the whole width (nt <= task_max_nt), the inverse-based
+// factorisation, either no augmented row or ONE short one whose tiles ride with the diagonal tasks and whose diagonal tile
+// nobody reads (EpiArgs::from_rows) — the shape of run_predict's factorisation of A at N <= 128 task_max_nt
+bool potrf_tasks_ok(const gpslc_ctx* c, int nt, int ntot, int short_rows, bool skip_aug_diag, int nb, const double* inv) {
+    static const int on = diag_env("GPSLC_TASKS", 1);
+    // one left-looking panel only: the panel knob of gpslc_set_tuning keeps its meaning
+    if (!on || !inv || nt < 2 || nt > std::min(std::min(c->task_max_nt, TASK_MAX_NT), std::max(1, c->panel)) || nb >= (1 << 20)) return false;
+    if (ntot == nt) return true;
+    return ntot == nt + 1 && short_rows > 0 && short_rows <= 32 && skip_aug_diag;
+}
+
+void potrf_tasks(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, long long inv_bstride, int* info, int info_base,
+                 int nb, hipStream_t st, int short_rows) {
+    size_t slot = 0;
+    for (size_t i = 0; i < c->streams.size(); ++i)
+        if (c->streams[i] == st) slot = i;
+    if (c->task_sync.size() <= slot) { c->task_sync.resize(slot + 1, nullptr); c->task_sync_ints.resize(slot + 1, 0); }
+    const size_t ints = TASK_SYNC_HDR + (size_t)TASK_SYNC_STRIDE * nb;
+    if (c->task_sync_ints[slot] < ints) {
+        if (c->task_sync[slot]) { HC(hipDeviceSynchronize()); HC(hipFree(c->task_sync[slot])); c->task_sync[slot] = nullptr; }
+        HC(hipMalloc((void**)&c->task_sync[slot], ints * sizeof(int)));
+        c->task_sync_ints[slot] = ints;
+    }
+    const int aug = ntot > nt ? 1 : 0;
+    static const int g_env = diag_env("GPSLC_TASK_G", 0);
+    const TaskList& tl = task_list_for(c, nt, aug, nb, g_env > 0 ? g_env : c->task_group);
+    HC(hipMemsetAsync(c->task_sync[slot], 0, ints * sizeof(int), st));
+    PotrfTaskArgs a{};
+    a.g.A = M; a.g.B = M; a.g.C = M;
+    a.g.F = TRef{inv, inv_bstride, 1, 0, 0, 0};
+    a.g.shape = 1; a.g.k0 = 0; a.g.accumulate = 1; a.g.fuse = 1; a.g.nbatch = nb;
+    a.g.short_row0 = nt; a.g.short_rows = aug ? short_rows : 0; a.g.sym = aug ? 3 : 2;
+    a.g.info = info; a.g.info_base = info_base;
+    a.list = tl.dev; a.sync = c->task_sync[slot]; a.nt = nt;
+    a.fence_mode = diag_env("GPSLC_TASK_FENCE", 0);
+    c->task_used = true;
+    const double Np = (double)nt * GP_TS;
+#ifdef GPSLC_DIAG
+    // measurement build, GPSLC_TASK_DBG=<n>: per-task stamps of the n-th launch -> gpurun_out/task_dbg.bin (tools/task_stamps.py)
+    static const int dbg_at = diag_env("GPSLC_TASK_DBG", 0);
+    static int dbg_seen = 0;
+    DevBuf dbg_buf;
+    if (dbg_at > 0 && ++dbg_seen == dbg_at) {
+        dbg_buf.alloc((size_t)tl.ntasks * 64);
+        HC(hipMemset(dbg_buf.p, 0, (size_t)tl.ntasks * 64));
+        a.dbg = dbg_buf.as<unsigned long long>();
+    }
+#endif
+    {
+        ProfScope ps(c, 4, (Np * Np * Np / 3.0 + (double)a.g.short_rows * Np * Np) * (double)nb, st);
+        launch_potrf_tasks(a, tl.ntasks, aug ? (short_rows + 15) / 16 : 0, st);
+    }
+    HC(hipGetLastError());
+#ifdef GPSLC_DIAG
+    if (dbg_buf.p) {
+        HC(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)tl.ntasks * 8);
+        HC(hipMemcpy(h.data(), dbg_buf.p, h.size() * 8, hipMemcpyDeviceToHost));
+        FILE* f = fopen("gpurun_out/task_dbg.bin", "wb");
+        if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
+#endif
+}
+
+// after the call's streams have drained: a time-out inside a persistent factorisation launch is an internal error
+void check_task_timeout(gpslc_ctx* c) {
+    if (!c->task_used) return;
+    c->task_used = false;
+    for (size_t i = 0; i < c->task_sync.size(); ++i) {
+        if (!c->task_sync[i]) continue;
+        int w = 0;
+        HC(hipMemcpy(&w, c->task_sync[i] + 8, sizeof(int), hipMemcpyDeviceToHost));
+        if (w != 0) throw std::runtime_error("persistent factorisation launch timed out waiting for a producer task");
+    }
+}
+
 // Blocked Cholesky of the leading nt x nt tiles of the lower-packed ntot x ntot tile matrix M; the
 // rows nt..ntot-1 are carried along (augmented rows): after the call they hold R = rows * L^-T and the
 // trailing (ntot-nt)^2 block its Schur complement.  Panels of `pw` tile columns: left-looking inside a
 // panel, one right-looking trailing update (K = pw*128) per panel.
 void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, long long inv_bstride,
                  int* info, int info_base, int nb, hipStream_t st, int aug_rows = 0, int prof_base = 0,
-                 bool robust = false, int info_div = 1, bool skip_aug_diag = false) {
+                 bool robust = false, int info_div = 1, bool skip_aug_diag = false, bool tasks = false) {
     // aug_rows > 0: the tile rows nt.. hold only that many live rows in total (right-hand sides);
     // a single augmented tile row is the common case and the only one the kernel shortens
     const int short_rows = (aug_rows > 0 && ntot == nt + 1) ? aug_rows : 0;
@@ -425,6 +580,12 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             }
         }
         HC(hipGetLastError());
+        return;
+    }
+    // small tile counts: the whole factorisation as ONE persistent launch of tile tasks (the caller checks its time-out word
+    // when the streams have drained: check_task_timeout)
+    if (tasks && info_div == 1 && prof_base == 0 && potrf_tasks_ok(c, nt, ntot, short_rows, skip_aug_diag, nb, inv)) {
+        potrf_tasks(c, M, nt, ntot, inv, inv_bstride, info, info_base, nb, st, short_rows);
         return;
     }
     for (int k = 0; k < nt; ++k) {
@@ -675,7 +836,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         // NB: the MeanITE pass takes K alpha as Y - yNoise alpha (k_solve.hip, ite_mean_kernel): it relies on alpha solving
         // EXACTLY (K_gram + yNoise I) alpha = Y.  Any future jitter, robust fallback or different right-hand side in this
         // factorisation must be reflected there (tests: test_mean_ite_tiny_noise_and_near_coincident_levels).
-        potrf_tiles(c, M, nt, ntot, inv, inv_bs, io.info + s0, 0, nb, st, (with_sums ? L : 0) + 1, 0, false, 1, epi_rows);
+        potrf_tiles(c, M, nt, ntot, inv, inv_bs, io.info + s0, 0, nb, st, (with_sums ? L : 0) + 1, 0, false, 1, epi_rows, /*tasks=*/true);
 
         EpiArgs ea{};
         ea.M = M; ea.n = n; ea.nt = nt; ea.naug = naug; ea.L = with_sums ? L : 0; ea.s0 = s0; ea.S = io.S;
@@ -813,6 +974,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
     }
     for (auto st : c->streams) HC(hipStreamSynchronize(st));
     HC(hipGetLastError());
+    check_task_timeout(c);
     if (c->flags & GPSLC_FLAG_PROFILE) prof_collect(c);
     c->last_info.resize(io.S);
     HC(hipMemcpy(c->last_info.data(), io.info, sizeof(int) * io.S, hipMemcpyDeviceToHost));
@@ -834,6 +996,9 @@ int guarded(gpslc_ctx* c, F&& f) {
     } catch (const std::bad_alloc&) {
         set_err(c, "device workspace allocation failed");
         return GPSLC_ERR_NOMEM;
+    } catch (const std::runtime_error& e) {
+        set_err(c, std::string("internal error: ") + e.what());
+        return GPSLC_ERR_INTERNAL;
     } catch (...) {
         set_err(c, "internal error");
         return GPSLC_ERR_INTERNAL;
@@ -1133,6 +1298,8 @@ int gpslc_destroy(gpslc_ctx* c) {
     for (auto s : c->streams) (void)hipStreamDestroy(s);
     for (auto& a : c->arenas) if (a.base) (void)hipFree(a.base);
     for (int* q : c->queues) if (q) (void)hipFree(q);
+    for (int* q : c->task_sync) if (q) (void)hipFree(q);
+    for (auto& t : c->task_lists) if (t.dev) (void)hipFree(t.dev);
     if (c->scratch.base) (void)hipFree(c->scratch.base);
     c->io.release();
     if (c->pin) (void)hipHostFree(c->pin);
@@ -1185,6 +1352,15 @@ int gpslc_set_tuning(gpslc_ctx* c, int32_t max_batch, int32_t panel_tiles, int32
     if (max_batch > 0) c->max_batch = max_batch;
     if (panel_tiles > 0) c->panel = panel_tiles;
     if (n_streams > 0) c->nstreams = n_streams;
+    return GPSLC_OK;
+}
+
+int gpslc_set_task_schedule(gpslc_ctx* c, int32_t max_tiles, int32_t group) {
+    if (!c) return -1;
+    if (max_tiles > TASK_MAX_NT) return -2;
+    if (group > 4096) return -3;
+    if (max_tiles >= 0) c->task_max_nt = max_tiles;
+    if (group > 0) c->task_group = group;
     return GPSLC_OK;
 }
 
@@ -1993,7 +2169,7 @@ int gpslc_profile_reset(gpslc_ctx* c) {
 }
 int gpslc_profile_get_class(gpslc_ctx* c, int32_t cls, int64_t* launches, double* total_ms, double* total_flop) {
     if (!c) return -1;
-    if (cls < 0 || cls >= kProfClasses) return bad_arg(c, 2, "kernel class must be 0..3");
+    if (cls < 0 || cls >= kProfClasses) return bad_arg(c, 2, "kernel class must be 0..4");
     if (launches) *launches = c->prof_launches[cls];
     if (total_ms) *total_ms = c->prof_ms[cls];
     if (total_flop) *total_flop = c->prof_flop[cls];

@@ -134,6 +134,34 @@ struct GramArgs {
     unsigned long long* dbg;   // measurement build only: per-workgroup s_memtime stamps [entry, staged, columns done, end], or null
 };
 
+// ---------------------------------------------------------------------------------------
+// The whole left-looking factorisation of a batch as ONE persistent launch (round 6, k_tilegemm.hip: potrf_tasks_kernel).
+// Tasks: diag(k) = update + Cholesky + inverse of diagonal tile k (the body of diag_update_potrf_kernel; k = 0: of
+// diag_potrf_inv_la_kernel), strip(i, k) = column update + panel product of tile (i, k) (a work item of tile_fused_strip_kernel).
+// The host lays the tasks of a launch out as eight ticket queues (one per XCD: a matrix never leaves its queue, so the
+// 7 - k strips of a column share the B panel in one L2) in an order in which every task follows its producers; progress
+// words per matrix in global memory carry the dependencies between workgroups (agent-scope release / acquire).
+// ---------------------------------------------------------------------------------------
+#define TASK_NONE 0xFFFFFFFFu
+#define TASK_LIST_HDR 32          // words: [0, 8) first descriptor of queue x, [8, 16) descriptors of queue x
+#define TASK_SYNC_HDR 32          // ints: [0, 8) ticket heads, [8] time-out word, [9] tasks finished
+#define TASK_SYNC_STRIDE 32       // ints per matrix: [0] diagonal tiles finished, [1 + i] finished tiles of tile row i (i <= nt)
+#define TASK_MAX_NT 24
+// descriptor: bits 0..19 batch element, 20..24 column k, 25..29 tile row i, 30: 1 = diag(k)
+__host__ __device__ inline unsigned task_pack(int b, int k, int i, int diag) {
+    return (unsigned)b | ((unsigned)k << 20) | ((unsigned)i << 25) | ((unsigned)diag << 30);
+}
+struct PotrfTaskArgs {
+    GemmArgs g;             // A = B = C = the tile matrix, F = the inverted diagonal blocks, k0 = 0, short_row0 = nt, short_rows,
+                            // sym = 3 with an augmented row riding along, info / info_base, nbatch
+    const unsigned* list;   // TASK_LIST_HDR header words, then the descriptors of the eight queues
+    int* sync;              // TASK_SYNC_HDR + TASK_SYNC_STRIDE * nbatch ints, zeroed by the launcher's caller before every launch
+    int nt;
+    int fence_mode;         // measurement build only (0 = release / acquire as documented)
+    unsigned long long* dbg;   // measurement build only: per-task stamps, or null
+};
+void launch_potrf_tasks(const PotrfTaskArgs& a, long long ntasks, int mt, hipStream_t st);
+
 // launchers (implemented in the k_*.hip files); all asynchronous on `st`
 void launch_tile_gemm(const GemmArgs& g, hipStream_t st);
 void launch_syrk_diag(const GemmArgs& g, int carry_aug, hipStream_t st);   // g.mi full-size diagonal tiles from (i0, i0)

@@ -38,9 +38,11 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #ifdef GPSLC_DIAG
 #define GP_DBG_ON(g) ((g).dbg != nullptr)
 #define GP_DIAG_SKIP(g) ((g).diag_skip)
+#define GP_FENCE_MODE(a) ((a).fence_mode)
 #else
 #define GP_DBG_ON(g) false
 #define GP_DIAG_SKIP(g) 0
+#define GP_FENCE_MODE(a) 0
 #endif
 
 // The trailing-update kernel raises its waves' issue priority around the 64 MFMAs of a slab (s_setprio 1) and drops it for
@@ -781,6 +783,168 @@ void launch_diag_update_potrf(const GemmArgs& g, int carry_aug, hipStream_t st) 
     if (mt == 0) launch_diag_update_potrf_t<0>(g, st);
     else if (mt == 1) launch_diag_update_potrf_t<1>(g, st);
     else launch_diag_update_potrf_t<2>(g, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// The whole left-looking factorisation of a batch in ONE persistent launch (round 6).
+// A workgroup draws a ticket from its XCD's queue (the queue is chosen by the hardware XCC_ID, not by blockIdx: the
+// strips of one matrix column then really share one L2; a workgroup whose queue has run dry goes on with the next
+// queue, so every task is executed whatever the placement), reads the task descriptor the host laid out
+// (PotrfTaskArgs::list), waits for the task's producers on the matrix's progress words, runs the body — exactly the
+// device functions of the per-column launches: strip_item, syrk_chain_wave + diag_potrf_inv_la_body, so every tile
+// receives the same MFMA chains in the same order and the factor is bit-identical — and publishes its own progress.
+// Hand-off between workgroups (MI355X_MICROARCH.md "inter-workgroup visibility", the plain-store form): every storing wave
+// drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane: agent-scope release fence, vmcnt(0) again (ROCm 7.2 can
+// drop the fence's own wait), relaxed agent-scope store of the progress word; consumer: ONE lane polls relaxed (bounded,
+// with s_sleep), ONE agent-scope acquire fence, vmcnt(0), workgroup barrier, then ordinary loads.
+// No deadlock: inside a queue every task follows its producers (host order), tickets are handed out in that order, and
+// a workgroup that holds a ticket is running — the oldest unfinished ticket never waits for anything unfinished.
+// A poll that exceeds its bound (a bug, never a schedule) sets the time-out word: every workgroup then stops waiting, the
+// launch drains, and the host reports GPSLC_ERR_INTERNAL instead of a hung GPU.
+// ---------------------------------------------------------------------------------------
+#define TASK_POLL_LIMIT (1 << 20)
+
+__device__ __forceinline__ int task_progress_load(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one lane: wait until *p >= need (or the launch has timed out)
+__device__ __forceinline__ void task_wait(const int* p, int need, int* tmo) {
+    if (task_progress_load(p) >= need) return;
+    for (int spins = 0;; ++spins) {
+        __builtin_amdgcn_s_sleep(8);
+        if (task_progress_load(p) >= need) return;
+        if ((spins & 63) == 63 && task_progress_load(tmo) != 0) return;
+        if (spins > TASK_POLL_LIMIT) {
+            __hip_atomic_store(tmo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // the fetching lane's state lives in LDS, and everything a body needs is recomputed from the thread index inside its
+    // branch: the strip body and the diagonal body each fill the register file on their own (248 / 254 VGPRs), so nothing
+    // but the thread index may stay live across them
+    __shared__ unsigned s_desc;
+    __shared__ int s_q, s_visited;
+    __shared__ unsigned long long s_ready;      // measurement build only
+    if (threadIdx.x == 0) {
+        s_q = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7);      // HW_REG_XCC_ID: this workgroup's XCD
+        s_visited = 0;                                                     // queues found empty so far
+    }
+    for (;;) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));          // opaque: nothing derived from it is hoisted out of the task loop
+        unsigned long long stf = 0;
+        if (GP_DBG_ON(a)) stf = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            int* const qhead = a.sync;
+            int* const tmo = a.sync + 8;
+            unsigned d = TASK_NONE;
+            int q = s_q, visited = s_visited;
+            while (visited < 8) {
+                const int len = (int)a.list[8 + q];
+                const int t = len > 0 ? atomicAdd(&qhead[q], 1) : len;
+                if (t < len) { d = a.list[TASK_LIST_HDR + a.list[q] + t]; break; }
+                q = (q + 1) & 7;
+                ++visited;
+            }
+            s_q = q; s_visited = visited;
+            if (d != TASK_NONE) {
+                const int nt = a.nt;
+                const int b = (int)(d & 0xFFFFF), k = (int)((d >> 20) & 31), i = (int)((d >> 25) & 31);
+                const int* prog = a.sync + TASK_SYNC_HDR + (long long)b * TASK_SYNC_STRIDE;
+                if (d >> 30) {                      // diag(k): tile row k (and the augmented row) final up to column k - 1
+                    if (k > 0) {
+                        task_wait(prog + 1 + k, k, tmo);
+                        if (MT > 0) task_wait(prog + 1 + nt, k, tmo);
+                    }
+                } else {                            // strip(i, k): inv(L_kk) and tile row k (diag(k)), tile row i up to column k - 1
+                    task_wait(prog, k + 1, tmo);
+                    if (i < nt && k > 0) task_wait(prog + 1 + i, k, tmo);
+                }
+                if (GP_DBG_ON(a)) s_ready = __builtin_amdgcn_s_memtime();       // producers done (before the acquire)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            s_desc = d;
+        }
+        __syncthreads();
+        const unsigned d = s_desc;
+        if (d == TASK_NONE) break;
+        const int b = (int)(d & 0xFFFFF), k = (int)((d >> 20) & 31), i = (int)((d >> 25) & 31);
+        const bool is_diag = (d >> 30) != 0;
+        unsigned long long st0 = 0, st1 = 0;
+        if (GP_DBG_ON(a)) st0 = __builtin_amdgcn_s_memtime();
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        if (is_diag) {
+            double* tile = tref_tile(a.g.C, b, k, k);
+            double* invt = tref_tile(a.g.F, b, 0, k);
+            if (k == 0) {
+                diag_potrf_inv_la_body(smem, tile, invt, a.g.info + b, a.g.info_base, tid, false);
+            } else {
+                switch (wave) {
+                    case 0: syrk_chain_wave<0, MT>(a.g, b, k, k, smem, tid, lane); break;
+                    case 1: syrk_chain_wave<1, MT>(a.g, b, k, k, smem, tid, lane); break;
+                    case 2: syrk_chain_wave<2, MT>(a.g, b, k, k, smem, tid, lane); break;
+                    default: syrk_chain_wave<3, MT>(a.g, b, k, k, smem, tid, lane); break;
+                }
+                diag_potrf_inv_la_body(smem, tile, invt, a.g.info + b, a.g.info_base + GP_TS * k, tid, true);
+            }
+        } else {
+            const int li = lane & 15, lg = lane >> 4;
+            int loff[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = tid + 256 * u;
+                loff[u] = (q >> 6) * LROW + (q & 63) * 2;
+            }
+            GemmArgs gl = a.g;
+            gl.k1 = k;
+            gl.fk = k;
+            strip_item<FUSE_WD>(gl, b, i, k, /*no_update=*/i >= a.nt, 8 * k, smem, smem + 2 * OPER_LDS, tid, lane, wave, li, lg,
+                                lg * LROW + 32 * wave + li, lg * LROW + li, loff, 0);
+        }
+        // publish: every wave's stores have left the CU, then one lane releases and moves the matrix's progress word
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (GP_DBG_ON(a)) st1 = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            int* prog = a.sync + TASK_SYNC_HDR + (long long)b * TASK_SYNC_STRIDE;
+            if (GP_FENCE_MODE(a) == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(is_diag ? prog : prog + 1 + i, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (GP_DBG_ON(a)) {     // measurement build: fetch start, body start, body end, published, descriptor, workgroup, ready
+                unsigned long long* dd = a.dbg + 8 * (size_t)atomicAdd(a.sync + 9, 1);
+                dd[0] = stf; dd[1] = st0; dd[2] = st1; dd[3] = __builtin_amdgcn_s_memtime(); dd[4] = d; dd[5] = blockIdx.x;
+                dd[6] = s_ready; dd[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            }
+        }
+    }
+}
+
+template <int MT>
+static void launch_potrf_tasks_t(const PotrfTaskArgs& a, unsigned grid, hipStream_t st) {
+    static DeviceOnce once;
+    constexpr int bytes = DIAG3_LDS_BYTES > GEMM_LDS_BYTES ? DIAG3_LDS_BYTES : GEMM_LDS_BYTES;
+    lds_opt_in(once, (const void*)potrf_tasks_kernel<MT>, bytes);
+    hipLaunchKernelGGL(potrf_tasks_kernel<MT>, dim3(grid), dim3(256), bytes, st, a);
+}
+
+// mt: 16-row blocks of the augmented right-hand-side row that ride with the diagonal tasks (0: no augmented row)
+void launch_potrf_tasks(const PotrfTaskArgs& a, long long ntasks, int mt, hipStream_t st) {
+    if (ntasks <= 0) return;
+    int slots = 2 * device_cus();
+#ifdef GPSLC_DIAG
+    slots = diag_env("GPSLC_GEMM_SLOTS", slots);
+#endif
+    const unsigned grid = (unsigned)(ntasks < slots ? ntasks : slots);
+    if (mt == 0) launch_potrf_tasks_t<0>(a, grid, st);
+    else if (mt == 1) launch_potrf_tasks_t<1>(a, grid, st);
+    else launch_potrf_tasks_t<2>(a, grid, st);
 }
 
 // ---------------------------------------------------------------------------------------

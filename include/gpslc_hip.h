@@ -70,6 +70,15 @@ int gpslc_set_data_dev(gpslc_ctx* ctx, const double* X, const double* T, const d
  * width of the blocked Cholesky, number of HIP streams chunks are spread over. */
 int gpslc_set_tuning(gpslc_ctx* ctx, int32_t max_batch, int32_t panel_tiles, int32_t n_streams);
 
+/* Schedule of the factorisation at small tile counts (round 6; no reference counterpart: the reference factorises one
+ * matrix at a time, src/likelihood.jl:42-43, src/estimation.jl:46).  Matrices of at most max_tiles x max_tiles tiles of
+ * 128 (and at most panel_tiles wide: one left-looking panel) are factorised by ONE persistent launch of tile tasks —
+ * diagonal-tile and strip tasks of many matrices in flight at once, dependencies through per-matrix progress words —
+ * instead of one launch per tile column; the factor is bit-identical either way.  max_tiles: 0 = always one launch per
+ * column, negative = keep (default 8: N <= 1024), at most 24.  group: matrices per group of the task order, <= 0 = keep
+ * (default 8).  Returns 0, or minus the number of the offending argument. */
+int gpslc_set_task_schedule(gpslc_ctx* ctx, int32_t max_tiles, int32_t group);
+
 /* Placement of a call's posterior samples inside a larger ensemble, for the library's own normals (z_or_null == NULL):
  * after gpslc_set_ensemble(ctx, s_off, S_total) sample s, level l of gpslc_predict[_dev] draws from the Philox stream
  * (s_off + s) + S_total * l instead of s + S * l.  A rank of a sharded prediction that holds the samples [s0, s1) of
@@ -288,6 +297,8 @@ int gpslc_pack_load(const char* path, int64_t s0, int64_t s1, double* X, double*
  *   1  tile_fused_strip_kernel in the factorisation of A (in-panel column update + panel solve)        work = flop
  *   2  the predictive-draw kernels of a launch_draws call (normal generation + triangular product)      work = draws
  *   3  every f64-MFMA tile-update launch of the full-ITE-covariance path (W solve, SYRK, factor)        work = flop
+ *   4  potrf_tasks_kernel: the whole factorisation of A as one persistent launch (gpslc_set_task_schedule)
+ *      work = flop, textbook count n^3 / 3 + (right-hand sides) n^2 per matrix
  * gpslc_profile_get is class 0. */
 int gpslc_profile_reset(gpslc_ctx* ctx);
 int gpslc_profile_get(gpslc_ctx* ctx, int64_t* launches, double* total_ms, double* total_flop);

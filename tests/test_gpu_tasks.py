@@ -1,0 +1,96 @@
+"""The persistent factorisation launch (potrf_tasks_kernel, gpslc_set_task_schedule) against the one-launch-per-column
+schedule it replaces at small tile counts.  Both run the same device functions on every tile in the same order, so every
+output must be equal BIT FOR BIT — a stale read between two workgroups (a missing release / acquire, a task that starts
+before its producer has published) shows up as a difference, not as a tolerance question.  The work replaced:
+src/likelihood.jl:42-43, src/estimation.jl:46 (the reference factorises CovWWp three times per unit, one matrix at a time).
+Parity with the oracle at these sizes is covered by the other GPU suites, which now run through this launch by default."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert a.shape == b.shape
+    assert np.array_equal(a, b)
+
+
+def _both(gp, c, doT, max_batch=0, group=0, **kw):
+    out = []
+    for tiles in (8, 0):                       # persistent launch, one launch per column
+        g = cases.gpslc_object(gp, c)
+        g.ctx().set_task_schedule(tiles, group)
+        if max_batch:
+            g.ctx().set_tuning(max_batch, 0, 0)
+        out.append(gp.predict(g, doT, want_mean_ite=True, **kw))
+    return out
+
+
+@pytest.mark.parametrize("n,S,L", [(300, 37, 1), (1024, 70, 1), (1000, 9, 20), (640, 3, 31), (257, 1, 2)])
+def test_task_launch_equals_the_per_column_schedule_bit_for_bit(gp, n, S, L):
+    """nt = 2 ... 8 tiles per side, 1 / 2 blocks of augmented rows (L = 1, 20, 31), fewer matrices than queues (S = 1, 3:
+    workgroups on the other XCDs take tickets of the queues that hold work)."""
+    c = cases.make_case(n, "UX", False, S=S, seed=n + S)
+    doT = np.linspace(-0.5, 0.7, L)
+    a, b = _both(gp, c, doT)
+    for x, y in zip(a, b):
+        _same(x, y)
+
+
+@pytest.mark.parametrize("group", [1, 3, 64])
+def test_task_order_group_size_and_chunking_do_not_change_results(gp, group):
+    """Group size 1 puts a task right behind its producer in the queue (consumers really wait on the progress words);
+    chunks of 5 matrices leave queues with 0 or 1 matrix."""
+    c = cases.make_case(700, "UX", True, S=23, seed=4)
+    a, b = _both(gp, c, [0.0, 1.0], group=group)
+    for x, y in zip(a, b):
+        _same(x, y)
+    a, b = _both(gp, c, [0.0, 1.0], max_batch=5, group=group)
+    for x, y in zip(a, b):
+        _same(x, y)
+
+
+def test_task_launch_draws_and_logpdf_paths(gp):
+    """Unit B (full ITE covariance + draws) keeps its own schedule after the task launch has factorised A; the :Y score
+    (logdet and quadratic form from the same factorisation) goes through it too."""
+    c = cases.make_case(400, "UX", False, S=6, seed=9)
+    outs = []
+    for tiles in (8, 0):
+        g = cases.gpslc_object(gp, c)
+        g.ctx().set_task_schedule(tiles, 0)
+        ms, vs, mi, dr = gp.predict(g, [0.1, 0.6], want_mean_ite=True, spp=3, seed=5, want_draws=True)
+        outs.append((ms, vs, mi, dr, gp.yLogpdf(g)))
+    for x, y in zip(*outs):
+        _same(x, y)
+
+
+@pytest.mark.parametrize("bad", [0, 5])
+def test_failing_pivot_is_reported_by_the_task_launch(gp, bad):
+    """A negative yNoise makes A = K - 0.5 I indefinite for ONE posterior sample: the same 1-based pivot comes back from both
+    schedules (first and later queue, first and later tile column), and the other samples report 0."""
+    n, S = 520, 11
+    c = cases.make_case(n, "UX", False, S=S, seed=31)
+    c["yNoise"][bad] = -0.5
+    infos, per_sample = [], []
+    for tiles in (8, 0):
+        g = cases.gpslc_object(gp, c)
+        g.ctx().set_task_schedule(tiles, 0)
+        with pytest.raises(gp.PosDefException) as ei:
+            gp.predict(g, [0.3])
+        infos.append(ei.value.info)
+        per_sample.append(g.ctx().last_info(S))
+    assert infos[0] == infos[1] and 0 < infos[0] <= n
+    _same(per_sample[0], per_sample[1])
+    assert per_sample[0][bad] == infos[0] and not np.delete(per_sample[0], bad).any()
+
+
+def test_set_task_schedule_arguments(gp):
+    c = cases.make_case(24, "UX", False, S=2, seed=2)
+    g = cases.gpslc_object(gp, c)
+    lib, h = g.ctx().lib, g.ctx().h
+    assert lib.gpslc_set_task_schedule(h, 25, 0) == -2
+    assert lib.gpslc_set_task_schedule(h, 8, 5000) == -3
+    assert lib.gpslc_set_task_schedule(h, -1, 0) == 0
+    assert lib.gpslc_set_task_schedule(None, 8, 8) == -1
