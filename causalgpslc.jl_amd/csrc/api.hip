@@ -104,7 +104,7 @@ constexpr int kProfClasses = 5;
 // device-resident task list of one (tile count, augmented row, batch size, group size) shape of the persistent
 // factorisation launch (potrf_tasks_kernel); built once per shape and kept (see task_list_for)
 struct TaskList {
-    int nt = 0, aug = 0, nb = 0, G = 0;
+    int nt = 0, back = 0, nb = 0, G = 0;
     unsigned* dev = nullptr;
     long long ntasks = 0;
     unsigned long long used = 0;
@@ -408,11 +408,10 @@ TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstri
 // earlier: ~ G * (nt + nt (nt + 1) / 2) tickets, several rounds of the XCD's 64 workgroup slots — a consumer practically
 // never finds its producer unfinished), and (2) every stretch of the order mixes the latency-bound diagonal tasks of some
 // groups with the MFMA-bound strips of others.  Inside a stage the strips of one matrix are consecutive tickets: they run
-// at the same time on one XCD and share the B panel L(k, 0..k-1) in its L2.  The strip of tile row k + 1 and the augmented
-// row come first (the next diagonal task waits for exactly those two).
-std::vector<unsigned> build_task_list(int nt, int aug, int nb, int G, long long* ntasks_out) {
+// at the same time on one XCD and share the B panel L(k, 0..k-1) in its L2.
+std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, long long* ntasks_out) {
     std::vector<unsigned> out(TASK_LIST_HDR, 0u);
-    const int NS = 2 * nt;
+    const int NS = 2 * nt + (back ? 1 : 0);       // back: one more stage, the back-substitution of the finished factor
     long long total = 0;
     const int wq = nb >> 3, wrm = nb & 7;
     for (int x = 0; x < 8; ++x) {
@@ -426,10 +425,13 @@ std::vector<unsigned> build_task_list(int nt, int aug, int nb, int G, long long*
                 const int k = s >> 1;
                 for (int j = g * G; j < std::min(xc, (g + 1) * G); ++j) {
                     const int b = x0 + j;
-                    if ((s & 1) == 0) { out.push_back(task_pack(b, k, k, 1)); continue; }
-                    if (k + 1 < nt) out.push_back(task_pack(b, k, k + 1, 0));
-                    if (aug) out.push_back(task_pack(b, k, nt, 0));
-                    for (int i = k + 2; i < nt; ++i) out.push_back(task_pack(b, k, i, 0));
+                    if (s == 2 * nt) { out.push_back(task_pack(b, 0, 0, TASK_BACK)); continue; }
+                    if ((s & 1) == 0) { out.push_back(task_pack(b, k, k, TASK_DIAG)); continue; }
+                    // the strip of tile row k + 1 carries the augmented tile of the column (the next diagonal task waits for
+                    // exactly those two); the last column has no strip: its augmented tile is a task of its own
+                    if (k + 1 < nt) out.push_back(task_pack(b, k, k + 1, TASK_STRIP_AUG));
+                    else out.push_back(task_pack(b, k, nt, TASK_STRIP));
+                    for (int i = k + 2; i < nt; ++i) out.push_back(task_pack(b, k, i, TASK_STRIP));
                 }
             }
         out[x] = (unsigned)first;
@@ -440,9 +442,9 @@ std::vector<unsigned> build_task_list(int nt, int aug, int nb, int G, long long*
     return out;
 }
 
-const TaskList& task_list_for(gpslc_ctx* c, int nt, int aug, int nb, int G) {
+const TaskList& task_list_for(gpslc_ctx* c, int nt, int back, int nb, int G) {
     for (auto& t : c->task_lists)
-        if (t.nt == nt && t.aug == aug && t.nb == nb && t.G == G) { t.used = ++c->task_clock; return t; }
+        if (t.nt == nt && t.back == back && t.nb == nb && t.G == G) { t.used = ++c->task_clock; return t; }
     if (c->task_lists.size() >= 8) {       // evict the least recently used shape (nothing of it may still be in flight)
         size_t v = 0;
         for (size_t i = 1; i < c->task_lists.size(); ++i)
@@ -452,8 +454,8 @@ const TaskList& task_list_for(gpslc_ctx* c, int nt, int aug, int nb, int G) {
         c->task_lists.erase(c->task_lists.begin() + (long)v);
     }
     TaskList t;
-    t.nt = nt; t.aug = aug; t.nb = nb; t.G = G;
-    std::vector<unsigned> h = build_task_list(nt, aug, nb, G, &t.ntasks);
+    t.nt = nt; t.back = back; t.nb = nb; t.G = G;
+    std::vector<unsigned> h = build_task_list(nt, back, nb, G, &t.ntasks);
     HC(hipMalloc((void**)&t.dev, h.size() * sizeof(unsigned)));
     HC(hipMemcpy(t.dev, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     t.used = ++c->task_clock;
@@ -462,18 +464,19 @@ const TaskList& task_list_for(gpslc_ctx* c, int nt, int aug, int nb, int G) {
 }
 
 // the persistent launch serves: one left-looking panel over the whole width (nt <= task_max_nt), the inverse-based
-// factorisation, either no augmented row or ONE short one whose tiles ride with the diagonal tasks and whose diagonal tile
-// nobody reads (EpiArgs::from_rows) — the shape of run_predict's factorisation of A at N <= 128 task_max_nt
+// factorisation, ONE short augmented row whose tiles ride with the diagonal tasks and whose diagonal tile nobody reads
+// (EpiArgs::from_rows) — the shape of run_predict's factorisation of A at N <= 128 task_max_nt
 bool potrf_tasks_ok(const gpslc_ctx* c, int nt, int ntot, int short_rows, bool skip_aug_diag, int nb, const double* inv) {
     static const int on = diag_env("GPSLC_TASKS", 1);
     // one left-looking panel only: the panel knob of gpslc_set_tuning keeps its meaning
     if (!on || !inv || nt < 2 || nt > std::min(std::min(c->task_max_nt, TASK_MAX_NT), std::max(1, c->panel)) || nb >= (1 << 20)) return false;
-    if (ntot == nt) return true;
     return ntot == nt + 1 && short_rows > 0 && short_rows <= 32 && skip_aug_diag;
 }
 
+// back_alpha (optional, [nb][nt 128]): every matrix's task chain ends with its back-substitution alpha = L^-T z (z = right-hand
+// side 0 after the forward solve the factorisation carries): launch_backsolve's result, bit for bit
 void potrf_tasks(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, long long inv_bstride, int* info, int info_base,
-                 int nb, hipStream_t st, int short_rows) {
+                 int nb, hipStream_t st, int short_rows, double* back_alpha) {
     size_t slot = 0;
     for (size_t i = 0; i < c->streams.size(); ++i)
         if (c->streams[i] == st) slot = i;
@@ -484,18 +487,18 @@ void potrf_tasks(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
         HC(hipMalloc((void**)&c->task_sync[slot], ints * sizeof(int)));
         c->task_sync_ints[slot] = ints;
     }
-    const int aug = ntot > nt ? 1 : 0;
     static const int g_env = diag_env("GPSLC_TASK_G", 0);
-    const TaskList& tl = task_list_for(c, nt, aug, nb, g_env > 0 ? g_env : c->task_group);
+    const TaskList& tl = task_list_for(c, nt, back_alpha ? 1 : 0, nb, g_env > 0 ? g_env : c->task_group);
     HC(hipMemsetAsync(c->task_sync[slot], 0, ints * sizeof(int), st));
     PotrfTaskArgs a{};
     a.g.A = M; a.g.B = M; a.g.C = M;
     a.g.F = TRef{inv, inv_bstride, 1, 0, 0, 0};
     a.g.shape = 1; a.g.k0 = 0; a.g.accumulate = 1; a.g.fuse = 1; a.g.nbatch = nb;
-    a.g.short_row0 = nt; a.g.short_rows = aug ? short_rows : 0; a.g.sym = aug ? 3 : 2;
+    a.g.short_row0 = nt; a.g.short_rows = short_rows; a.g.sym = 3;
     a.g.info = info; a.g.info_base = info_base;
-    a.list = tl.dev; a.sync = c->task_sync[slot]; a.nt = nt;
-    a.fence_mode = diag_env("GPSLC_TASK_FENCE", 0);
+    a.list = tl.dev; a.sync = c->task_sync[slot]; a.nt = nt; a.alpha = back_alpha;
+    a.fence_mode = diag_env("GPSLC_TASK_FENCE", 0x30);      // measurement build: bit 0 = no release fence (WRONG results: the
+                                                            // price of the fence), bits 4..5 = priority of the diagonal tasks
     c->task_used = true;
     const double Np = (double)nt * GP_TS;
 #ifdef GPSLC_DIAG
@@ -511,7 +514,7 @@ void potrf_tasks(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
 #endif
     {
         ProfScope ps(c, 4, (Np * Np * Np / 3.0 + (double)a.g.short_rows * Np * Np) * (double)nb, st);
-        launch_potrf_tasks(a, tl.ntasks, aug ? (short_rows + 15) / 16 : 0, st);
+        launch_potrf_tasks(a, tl.ntasks, (short_rows + 15) / 16, st);
     }
     HC(hipGetLastError());
 #ifdef GPSLC_DIAG
@@ -541,9 +544,13 @@ void check_task_timeout(gpslc_ctx* c) {
 // rows nt..ntot-1 are carried along (augmented rows): after the call they hold R = rows * L^-T and the
 // trailing (ntot-nt)^2 block its Schur complement.  Panels of `pw` tile columns: left-looking inside a
 // panel, one right-looking trailing update (K = pw*128) per panel.
-void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, long long inv_bstride,
+// tasks: the caller checks the persistent launch's time-out word when its streams have drained (check_task_timeout);
+// back_alpha: where the back-substitution alpha = L^-T z may be delivered by that launch.  Returns true when it was (the
+// caller then skips launch_backsolve).
+bool potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, long long inv_bstride,
                  int* info, int info_base, int nb, hipStream_t st, int aug_rows = 0, int prof_base = 0,
-                 bool robust = false, int info_div = 1, bool skip_aug_diag = false, bool tasks = false) {
+                 bool robust = false, int info_div = 1, bool skip_aug_diag = false, bool tasks = false,
+                 double* back_alpha = nullptr) {
     // aug_rows > 0: the tile rows nt.. hold only that many live rows in total (right-hand sides);
     // a single augmented tile row is the common case and the only one the kernel shortens
     const int short_rows = (aug_rows > 0 && ntot == nt + 1) ? aug_rows : 0;
@@ -580,13 +587,12 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             }
         }
         HC(hipGetLastError());
-        return;
+        return false;
     }
-    // small tile counts: the whole factorisation as ONE persistent launch of tile tasks (the caller checks its time-out word
-    // when the streams have drained: check_task_timeout)
+    // small tile counts: the whole factorisation (and the back-substitution) as ONE persistent launch of tile tasks
     if (tasks && info_div == 1 && prof_base == 0 && potrf_tasks_ok(c, nt, ntot, short_rows, skip_aug_diag, nb, inv)) {
-        potrf_tasks(c, M, nt, ntot, inv, inv_bstride, info, info_base, nb, st, short_rows);
-        return;
+        potrf_tasks(c, M, nt, ntot, inv, inv_bstride, info, info_base, nb, st, short_rows, back_alpha);
+        return back_alpha != nullptr;
     }
     for (int k = 0; k < nt; ++k) {
         const int ka = (k / pw) * pw;
@@ -654,6 +660,7 @@ void potrf_tiles(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
             gemm(c, g, st, prof_base);
         }
     }
+    return false;
 }
 
 struct PredictIO {
@@ -836,7 +843,8 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         // NB: the MeanITE pass takes K alpha as Y - yNoise alpha (k_solve.hip, ite_mean_kernel): it relies on alpha solving
         // EXACTLY (K_gram + yNoise I) alpha = Y.  Any future jitter, robust fallback or different right-hand side in this
         // factorisation must be reflected there (tests: test_mean_ite_tiny_noise_and_near_coincident_levels).
-        potrf_tiles(c, M, nt, ntot, inv, inv_bs, io.info + s0, 0, nb, st, (with_sums ? L : 0) + 1, 0, false, 1, epi_rows, /*tasks=*/true);
+        const bool back_done = potrf_tiles(c, M, nt, ntot, inv, inv_bs, io.info + s0, 0, nb, st, (with_sums ? L : 0) + 1, 0, false, 1,
+                                           epi_rows, /*tasks=*/true, want_mean ? zwork + (long long)nb * Np : nullptr);
 
         EpiArgs ea{};
         ea.M = M; ea.n = n; ea.nt = nt; ea.naug = naug; ea.L = with_sums ? L : 0; ea.s0 = s0; ea.S = io.S;
@@ -848,7 +856,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         if (want_mean) {
             BackArgs ba{};
             ba.M = M; ba.inv = inv; ba.inv_bstride = inv_bs; ba.nt = nt; ba.naug = naug; ba.zwork = zwork;
-            launch_backsolve(ba, nb, st);
+            if (!back_done) launch_backsolve(ba, nb, st);
             const double* alpha = zwork + (long long)nb * Np;
             IteMeanArgs ia{};
             ia.X = io.X; ia.T = c->dT; ia.p = io.p; ia.s0 = s0; ia.S = io.S;

@@ -2,6 +2,7 @@
 // construction of D / Delta for the full ITE covariance, CovITE gather and the predictive draws.
 #include "gpslc_internal.h"
 #include "gp_math.h"
+#include "back_block.h"
 
 #define MAXF 32
 
@@ -10,26 +11,6 @@
 // alpha_i = inv(L_ii)^T z_i (one workgroup per matrix), then z_k -= L(i,k)^T alpha_i for every k < i
 // (one workgroup per tile; reads L exactly once: HBM-bound).
 // ---------------------------------------------------------------------------------------
-// (t^T v)_c for the 32 columns c = wave*32 .. +31 of a column-major 128 x 128 tile: every lane loads its
-// two rows of all 32 columns first (64 independent 8-byte loads in flight), then the wave reduces.
-__device__ __forceinline__ void tile_tv32(const double* __restrict__ t, const double* v /*LDS[128]*/,
-                                          int wave, int lane, double out[32]) {
-    const double v0 = v[lane], v1 = v[lane + 64];
-    double p[32];
-#pragma unroll
-    for (int cc = 0; cc < 32; ++cc) {
-        const double* col = t + (wave * 32 + cc) * GP_TS;
-        p[cc] = col[lane] * v0 + col[lane + 64] * v1;
-    }
-#pragma unroll
-    for (int cc = 0; cc < 32; ++cc) {
-        double x = p[cc];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
-        out[cc] = x;
-    }
-}
-
 // alpha_i = inv(L_ii)^T z_i, one workgroup per matrix
 __global__ __launch_bounds__(256) void backsolve_alpha_kernel(BackArgs a, int i, double* alpha) {
     __shared__ double zi[GP_TS];

@@ -30,6 +30,7 @@
 //     workgroups that share an L2 work on neighbouring tiles of the same matrices.
 #include "gpslc_internal.h"
 #include "diag_block.h"
+#include "back_block.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -38,11 +39,13 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #ifdef GPSLC_DIAG
 #define GP_DBG_ON(g) ((g).dbg != nullptr)
 #define GP_DIAG_SKIP(g) ((g).diag_skip)
-#define GP_FENCE_MODE(a) ((a).fence_mode)
+#define GP_FENCE_MODE(a) ((a).fence_mode & 1)
+#define GP_TASK_PRIO(a) (((a).fence_mode >> 4) & 3)      // GPSLC_TASK_FENCE bits 4..5: priority of the diagonal tasks
 #else
 #define GP_DBG_ON(g) false
 #define GP_DIAG_SKIP(g) 0
 #define GP_FENCE_MODE(a) 0
+#define GP_TASK_PRIO(a) 3
 #endif
 
 // The trailing-update kernel raises its waves' issue priority around the 64 MFMAs of a slab (s_setprio 1) and drops it for
@@ -414,11 +417,15 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------
 // One work item of the strip kernel: tile (ti, tj) of batch element b.  no_update: the tile needs the panel product
 // only (its column update was done elsewhere, or there is none: first column of a panel).
-template <int WD>
+// AUGEP (task kernel only): the item also applies the panel product to the augmented right-hand-side tile (short_row0, tj) of
+// its column — the tile diag(tj) has already updated — instead of that tile being a work item of its own: all four waves load
+// its live rows, wave w computes the column blocks w and 7 - w.  Per output element the same MFMA chain as the stand-alone
+// item (ascending column block of X, then v): bit-identical.
+template <int WD, bool AUGEP = false>
 __device__ __forceinline__ void strip_item(const GemmArgs& g, const int b, const int ti, const int tj, const bool no_update,
                                            const int nslab, double* lA, double* lB, const int tid, const int lane,
                                            const int wave, const int li, const int lg, const int frow_a, const int frow_b,
-                                           const int (&loff)[4], const long long item) {
+                                           const int (&loff)[4], const long long item, const bool with_aug = false) {
     double* __restrict__ Ct = tref_tile(g.C, b, ti, tj);
     // augmented right-hand-side tiles hold `short_rows` live rows: a wave whose strip lies below them only helps
     // with the staging (its rows keep their zeros: never loaded, never stored)
@@ -531,6 +538,51 @@ __device__ __forceinline__ void strip_item(const GemmArgs& g, const int b, const
                 __builtin_nontemporal_store(st[0][v], Co + (16 * nc + 4 * v) * GP_TS);
                 __builtin_nontemporal_store(st[1][v], Co + (16 * nc + 4 * v) * GP_TS + 16);
             }
+        }
+    }
+    if (AUGEP && with_aug) {
+        const int mrows = (g.short_rows + 15) >> 4;           // live 16-row blocks of the augmented tile (1 or 2)
+        double* __restrict__ Cg = tref_tile(g.C, b, g.short_row0, tj) + (lg * GP_TS + li);
+        const double* __restrict__ Wl = tref_tile(g.F, b, 0, g.fk) + (lg * GP_TS + li);
+        d4 ag[2][8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    if (m < mrows) ag[m][n][v] = Cg[(16 * n + 4 * v) * GP_TS + 16 * m];
+        auto colblock = [&](auto ncc) {
+            constexpr int nc = decltype(ncc)::value;
+            double wf[nc + 1][4];
+#pragma unroll
+            for (int n = 0; n <= nc; ++n)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) wf[n][v] = Wl[(16 * n + 4 * v) * GP_TS + 16 * nc];
+            d4 st[2];
+            st[0] = (d4){0.0, 0.0, 0.0, 0.0};
+            st[1] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int n = 0; n <= nc; ++n)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    st[0] = mfma_step<0>(wf[n][v], ag[0][n][v], st[0]);
+                    if (mrows > 1) st[1] = mfma_step<0>(wf[n][v], ag[1][n][v], st[1]);
+                }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                Cg[(16 * nc + 4 * v) * GP_TS] = st[0][v];
+                if (mrows > 1) Cg[(16 * nc + 4 * v) * GP_TS + 16] = st[1][v];
+            }
+        };
+        // every wave has read the whole tile before any wave overwrites a column block of it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        switch (wave) {
+            case 0: colblock(std::integral_constant<int, 0>()); colblock(std::integral_constant<int, 7>()); break;
+            case 1: colblock(std::integral_constant<int, 1>()); colblock(std::integral_constant<int, 6>()); break;
+            case 2: colblock(std::integral_constant<int, 2>()); colblock(std::integral_constant<int, 5>()); break;
+            default: colblock(std::integral_constant<int, 3>()); colblock(std::integral_constant<int, 4>()); break;
         }
     }
     if (GP_DBG_ON(g)) {
@@ -821,18 +873,33 @@ __device__ __forceinline__ void task_wait(const int* p, int need, int* tmo) {
     }
 }
 
+// lane 0 of a workgroup: the next descriptor of queue `q` (or of the queues after it once it has run dry: `visited` counts
+// the empty ones), TASK_NONE when all eight are exhausted
+__device__ __forceinline__ unsigned task_fetch(const PotrfTaskArgs& a, int& q, int& visited) {
+    while (visited < 8) {
+        const int len = (int)a.list[8 + q];
+        const int t = len > 0 ? atomicAdd(&a.sync[q], 1) : len;
+        if (t < len) return a.list[TASK_LIST_HDR + a.list[q] + t];
+        q = (q + 1) & 7;
+        ++visited;
+    }
+    return TASK_NONE;
+}
+
 template <int MT>
 __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // the fetching lane's state lives in LDS, and everything a body needs is recomputed from the thread index inside its
     // branch: the strip body and the diagonal body each fill the register file on their own (248 / 254 VGPRs), so nothing
-    // but the thread index may stay live across them
-    __shared__ unsigned s_desc;
+    // but the thread index (and lane 0's prefetched ticket) may stay live across them
+    __shared__ unsigned s_desc, s_next;
     __shared__ int s_q, s_visited;
     __shared__ unsigned long long s_ready;      // measurement build only
     if (threadIdx.x == 0) {
-        s_q = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7);      // HW_REG_XCC_ID: this workgroup's XCD
-        s_visited = 0;                                                     // queues found empty so far
+        int q = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7);     // HW_REG_XCC_ID: this workgroup's XCD
+        int visited = 0;                                                    // queues found empty so far
+        s_next = task_fetch(a, q, visited);
+        s_q = q; s_visited = visited;
     }
     for (;;) {
         int tid = threadIdx.x;
@@ -840,23 +907,16 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
         unsigned long long stf = 0;
         if (GP_DBG_ON(a)) stf = __builtin_amdgcn_s_memtime();
         if (tid == 0) {
-            int* const qhead = a.sync;
             int* const tmo = a.sync + 8;
-            unsigned d = TASK_NONE;
-            int q = s_q, visited = s_visited;
-            while (visited < 8) {
-                const int len = (int)a.list[8 + q];
-                const int t = len > 0 ? atomicAdd(&qhead[q], 1) : len;
-                if (t < len) { d = a.list[TASK_LIST_HDR + a.list[q] + t]; break; }
-                q = (q + 1) & 7;
-                ++visited;
-            }
-            s_q = q; s_visited = visited;
+            const unsigned d = s_next;
             if (d != TASK_NONE) {
                 const int nt = a.nt;
                 const int b = (int)(d & 0xFFFFF), k = (int)((d >> 20) & 31), i = (int)((d >> 25) & 31);
                 const int* prog = a.sync + TASK_SYNC_HDR + (long long)b * TASK_SYNC_STRIDE;
-                if (d >> 30) {                      // diag(k): tile row k (and the augmented row) final up to column k - 1
+                if ((d >> 30) == 3) {               // back-substitution: the whole factor and the solved augmented row
+                    task_wait(prog, nt, tmo);
+                    task_wait(prog + 1 + nt, nt, tmo);
+                } else if ((d >> 30) & 1) {         // diag(k): tile row k (and the augmented row) final up to column k - 1
                     if (k > 0) {
                         task_wait(prog + 1 + k, k, tmo);
                         if (MT > 0) task_wait(prog + 1 + nt, k, tmo);
@@ -875,12 +935,29 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
         const unsigned d = s_desc;
         if (d == TASK_NONE) break;
         const int b = (int)(d & 0xFFFFF), k = (int)((d >> 20) & 31), i = (int)((d >> 25) & 31);
-        const bool is_diag = (d >> 30) != 0;
+        const bool is_back = (d >> 30) == 3;
+        const bool is_diag = (d >> 30) == 1;
+        const bool with_aug = (d >> 30) == 2;       // strip(k + 1, k) also carries the augmented tile (nt, k)
         unsigned long long st0 = 0, st1 = 0;
         if (GP_DBG_ON(a)) st0 = __builtin_amdgcn_s_memtime();
+        // the ticket of the NEXT task is drawn now and read after the body: its round trip hides behind the tile
+        int tnext = 0, qn = 0, lenn = 0;
+        if (tid == 0) {
+            qn = s_q;
+            lenn = s_visited < 8 ? (int)a.list[8 + qn] : 0;
+            tnext = lenn > 0 ? atomicAdd(&a.sync[qn], 1) : 0;
+        }
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        if (is_diag) {
+        if (is_back) {
+            // alpha = L^-T z of this matrix (launch_backsolve's kernels as one task: an HBM stream of the factor beside the
+            // other workgroups' MFMA work); nobody in this launch reads alpha: no progress word to move
+            back_task_body(a.g.C, a.g.F, b, a.nt, a.alpha + (long long)b * a.nt * GP_TS, smem, tid);
+        } else if (is_diag) {
+            // the pivot chains of a diagonal task are dependent fp64 operations that share the SIMD's datapath with the partner
+            // workgroup's MFMA stream: at raised priority its instructions are issued first whenever they are ready
+            if (GP_TASK_PRIO(a) == 3) __builtin_amdgcn_s_setprio(3);
+            else if (GP_TASK_PRIO(a) == 1) __builtin_amdgcn_s_setprio(1);
             double* tile = tref_tile(a.g.C, b, k, k);
             double* invt = tref_tile(a.g.F, b, 0, k);
             if (k == 0) {
@@ -894,6 +971,7 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
                 }
                 diag_potrf_inv_la_body(smem, tile, invt, a.g.info + b, a.g.info_base + GP_TS * k, tid, true);
             }
+            __builtin_amdgcn_s_setprio(0);
         } else {
             const int li = lane & 15, lg = lane >> 4;
             int loff[4];
@@ -905,18 +983,32 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
             GemmArgs gl = a.g;
             gl.k1 = k;
             gl.fk = k;
-            strip_item<FUSE_WD>(gl, b, i, k, /*no_update=*/i >= a.nt, 8 * k, smem, smem + 2 * OPER_LDS, tid, lane, wave, li, lg,
-                                lg * LROW + 32 * wave + li, lg * LROW + li, loff, 0);
+            strip_item<FUSE_WD, (MT > 0)>(gl, b, i, k, /*no_update=*/i >= a.nt, 8 * k, smem, smem + 2 * OPER_LDS, tid, lane, wave,
+                                          li, lg, lg * LROW + 32 * wave + li, lg * LROW + li, loff, 0, with_aug);
         }
-        // publish: every wave's stores have left the CU, then one lane releases and moves the matrix's progress word
+        // publish: every wave's stores have left the CU, then one lane releases and moves the matrix's progress word(s)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (GP_DBG_ON(a)) st1 = __builtin_amdgcn_s_memtime();
         if (tid == 0) {
+            // the next descriptor travels under the release fence
+            unsigned dn = TASK_NONE;
+            const bool hit = tnext < lenn;
+            if (hit) dn = a.list[TASK_LIST_HDR + a.list[qn] + tnext];
             int* prog = a.sync + TASK_SYNC_HDR + (long long)b * TASK_SYNC_STRIDE;
-            if (GP_FENCE_MODE(a) == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(is_diag ? prog : prog + 1 + i, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!is_back) {
+                if (GP_FENCE_MODE(a) == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(is_diag ? prog : prog + 1 + i, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (with_aug) __hip_atomic_store(prog + 1 + a.nt, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!hit) {                      // this queue has run dry (or had long before): go on with the others
+                int q = qn, visited = s_visited;
+                if (visited < 8) { q = (q + 1) & 7; ++visited; }
+                dn = task_fetch(a, q, visited);
+                s_q = q; s_visited = visited;
+            }
+            s_next = dn;
             if (GP_DBG_ON(a)) {     // measurement build: fetch start, body start, body end, published, descriptor, workgroup, ready
                 unsigned long long* dd = a.dbg + 8 * (size_t)atomicAdd(a.sync + 9, 1);
                 dd[0] = stf; dd[1] = st0; dd[2] = st1; dd[3] = __builtin_amdgcn_s_memtime(); dd[4] = d; dd[5] = blockIdx.x;
@@ -934,7 +1026,7 @@ static void launch_potrf_tasks_t(const PotrfTaskArgs& a, unsigned grid, hipStrea
     hipLaunchKernelGGL(potrf_tasks_kernel<MT>, dim3(grid), dim3(256), bytes, st, a);
 }
 
-// mt: 16-row blocks of the augmented right-hand-side row that ride with the diagonal tasks (0: no augmented row)
+// mt: 16-row blocks (1 or 2) of the augmented right-hand-side row that ride with the diagonal tasks
 void launch_potrf_tasks(const PotrfTaskArgs& a, long long ntasks, int mt, hipStream_t st) {
     if (ntasks <= 0) return;
     int slots = 2 * device_cus();
@@ -942,8 +1034,7 @@ void launch_potrf_tasks(const PotrfTaskArgs& a, long long ntasks, int mt, hipStr
     slots = diag_env("GPSLC_GEMM_SLOTS", slots);
 #endif
     const unsigned grid = (unsigned)(ntasks < slots ? ntasks : slots);
-    if (mt == 0) launch_potrf_tasks_t<0>(a, grid, st);
-    else if (mt == 1) launch_potrf_tasks_t<1>(a, grid, st);
+    if (mt <= 1) launch_potrf_tasks_t<1>(a, grid, st);
     else launch_potrf_tasks_t<2>(a, grid, st);
 }
 

@@ -9,10 +9,13 @@ import numpy as np
 d = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
 d = d[d[:, 3] > 0]
 desc = d[:, 4]
-kind = (desc >> np.uint64(30)) & np.uint64(1)
+kind4 = (desc >> np.uint64(30)).astype(int)          # 0 strip, 1 diag, 2 strip + augmented tile, 3 back-substitution
+kind = (kind4 == 1).astype(int)
+isback = kind4 == 3
 k = ((desc >> np.uint64(20)) & np.uint64(31)).astype(int)
 i = ((desc >> np.uint64(25)) & np.uint64(31)).astype(int)
-nt = int(i[kind == 0].max()) if (kind == 0).any() else 0
+nt = int(i[(kind4 == 0) | (kind4 == 2)].max()) if ((kind4 == 0) | (kind4 == 2)).any() else 0
+kind = np.where(isback, 7, kind)
 t = d[:, :4].astype(np.int64)
 ready = d[:, 6].astype(np.int64)
 span = t[:, 3].max() - t[:, 0].min()
@@ -21,7 +24,7 @@ busy = (t[:, 3] - t[:, 0]).sum() / (len(np.unique(d[:, 5])) * span)
 print(f"workgroup busy fraction (fetch -> published) {busy:.3f}")
 print("| task | count | fetch+wait | of it waiting for producers | acquire+barrier | body | publish |")
 print("|---|---:|---:|---:|---:|---:|---:|")
-for name, sel in [("diag(0)", (kind == 1) & (k == 0)), ("diag(k>0)", (kind == 1) & (k > 0)),
+for name, sel in [("back-substitution", isback), ("diag(0)", (kind == 1) & (k == 0)), ("diag(k>0)", (kind == 1) & (k > 0)),
                   ("strip full", (kind == 0) & (i < nt)), ("strip aug", (kind == 0) & (i == nt))] + \
                  [(f"strip k={kk}", (kind == 0) & (i < nt) & (k == kk)) for kk in sorted(set(k[kind == 0]))] + \
                  [(f"diag k={kk}", (kind == 1) & (k == kk)) for kk in sorted(set(k[kind == 1]))]:
