@@ -104,7 +104,7 @@ constexpr int kProfClasses = 5;
 // device-resident task list of one (tile count, augmented row, batch size, group size) shape of the persistent
 // factorisation launch (potrf_tasks_kernel); built once per shape and kept (see task_list_for)
 struct TaskList {
-    int nt = 0, back = 0, nb = 0, G = 0;
+    int nt = 0, back = 0, nb = 0, G = 0, rows = 0;
     unsigned* dev = nullptr;
     long long ntasks = 0;
     unsigned long long used = 0;
@@ -135,8 +135,10 @@ struct gpslc_ctx {
     std::vector<TaskList> task_lists;
     unsigned long long task_clock = 0;
     bool task_used = false;
-    int task_max_nt = 8;           // tile counts up to this one take the persistent launch (N <= 1024)
+    int task_min_nt = 5, task_max_nt = 8;   // tile counts in this range take the persistent launch (640 <= N <= 1024: below,
+                                            // one launch per column is faster — N = 512: -5 %, profiles/r06_ab_experiments.md)
     int task_group = 8;            // matrices per group of the task order (see build_task_list)
+    int task_rows = 2;             // consecutive tile rows of a column per strip task
     Arena scratch;                 // call-level buffers (internal MeanITE of a draws-only call, ...)
     PoolArena io;                  // staging of the host-pointer entry points and per-call info words
     // single-launch small-n node scores (k_small.hip): pinned, device-visible host staging (descriptors, inputs,
@@ -409,7 +411,7 @@ TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstri
 // never finds its producer unfinished), and (2) every stretch of the order mixes the latency-bound diagonal tasks of some
 // groups with the MFMA-bound strips of others.  Inside a stage the strips of one matrix are consecutive tickets: they run
 // at the same time on one XCD and share the B panel L(k, 0..k-1) in its L2.
-std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, long long* ntasks_out) {
+std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, int rows_per_task, long long* ntasks_out) {
     std::vector<unsigned> out(TASK_LIST_HDR, 0u);
     const int NS = 2 * nt + (back ? 1 : 0);       // back: one more stage, the back-substitution of the finished factor
     long long total = 0;
@@ -431,7 +433,8 @@ std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, long long
                     // exactly those two); the last column has no strip: its augmented tile is a task of its own
                     if (k + 1 < nt) out.push_back(task_pack(b, k, k + 1, TASK_STRIP_AUG));
                     else out.push_back(task_pack(b, k, nt, TASK_STRIP));
-                    for (int i = k + 2; i < nt; ++i) out.push_back(task_pack(b, k, i, TASK_STRIP));
+                    for (int i = k + 2; i < nt; i += rows_per_task)
+                        out.push_back(task_pack(b, k, i, TASK_STRIP, std::min(rows_per_task, nt - i)));
                 }
             }
         out[x] = (unsigned)first;
@@ -442,9 +445,9 @@ std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, long long
     return out;
 }
 
-const TaskList& task_list_for(gpslc_ctx* c, int nt, int back, int nb, int G) {
+const TaskList& task_list_for(gpslc_ctx* c, int nt, int back, int nb, int G, int rows) {
     for (auto& t : c->task_lists)
-        if (t.nt == nt && t.back == back && t.nb == nb && t.G == G) { t.used = ++c->task_clock; return t; }
+        if (t.nt == nt && t.back == back && t.nb == nb && t.G == G && t.rows == rows) { t.used = ++c->task_clock; return t; }
     if (c->task_lists.size() >= 8) {       // evict the least recently used shape (nothing of it may still be in flight)
         size_t v = 0;
         for (size_t i = 1; i < c->task_lists.size(); ++i)
@@ -454,8 +457,8 @@ const TaskList& task_list_for(gpslc_ctx* c, int nt, int back, int nb, int G) {
         c->task_lists.erase(c->task_lists.begin() + (long)v);
     }
     TaskList t;
-    t.nt = nt; t.back = back; t.nb = nb; t.G = G;
-    std::vector<unsigned> h = build_task_list(nt, back, nb, G, &t.ntasks);
+    t.nt = nt; t.back = back; t.nb = nb; t.G = G; t.rows = rows;
+    std::vector<unsigned> h = build_task_list(nt, back, nb, G, rows, &t.ntasks);
     HC(hipMalloc((void**)&t.dev, h.size() * sizeof(unsigned)));
     HC(hipMemcpy(t.dev, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     t.used = ++c->task_clock;
@@ -469,7 +472,9 @@ const TaskList& task_list_for(gpslc_ctx* c, int nt, int back, int nb, int G) {
 bool potrf_tasks_ok(const gpslc_ctx* c, int nt, int ntot, int short_rows, bool skip_aug_diag, int nb, const double* inv) {
     static const int on = diag_env("GPSLC_TASKS", 1);
     // one left-looking panel only: the panel knob of gpslc_set_tuning keeps its meaning
-    if (!on || !inv || nt < 2 || nt > std::min(std::min(c->task_max_nt, TASK_MAX_NT), std::max(1, c->panel)) || nb >= (1 << 20)) return false;
+    if (!on || !inv || nt < std::max(2, c->task_min_nt) || nt > std::min(std::min(c->task_max_nt, TASK_MAX_NT), std::max(1, c->panel)) ||
+        nb >= TASK_MAX_BATCH)
+        return false;
     return ntot == nt + 1 && short_rows > 0 && short_rows <= 32 && skip_aug_diag;
 }
 
@@ -488,7 +493,9 @@ void potrf_tasks(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
         c->task_sync_ints[slot] = ints;
     }
     static const int g_env = diag_env("GPSLC_TASK_G", 0);
-    const TaskList& tl = task_list_for(c, nt, back_alpha ? 1 : 0, nb, g_env > 0 ? g_env : c->task_group);
+    static const int r_env = diag_env("GPSLC_TASK_ROWS", 0);
+    const TaskList& tl = task_list_for(c, nt, back_alpha ? 1 : 0, nb, g_env > 0 ? g_env : c->task_group,
+                                       std::max(1, std::min(4, r_env > 0 ? r_env : c->task_rows)));
     HC(hipMemsetAsync(c->task_sync[slot], 0, ints * sizeof(int), st));
     PotrfTaskArgs a{};
     a.g.A = M; a.g.B = M; a.g.C = M;
@@ -1363,10 +1370,12 @@ int gpslc_set_tuning(gpslc_ctx* c, int32_t max_batch, int32_t panel_tiles, int32
     return GPSLC_OK;
 }
 
-int gpslc_set_task_schedule(gpslc_ctx* c, int32_t max_tiles, int32_t group) {
+int gpslc_set_task_schedule(gpslc_ctx* c, int32_t min_tiles, int32_t max_tiles, int32_t group) {
     if (!c) return -1;
-    if (max_tiles > TASK_MAX_NT) return -2;
-    if (group > 4096) return -3;
+    if (min_tiles > TASK_MAX_NT) return -2;
+    if (max_tiles > TASK_MAX_NT) return -3;
+    if (group > 4096) return -4;
+    if (min_tiles > 0) c->task_min_nt = min_tiles;
     if (max_tiles >= 0) c->task_max_nt = max_tiles;
     if (group > 0) c->task_group = group;
     return GPSLC_OK;

@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
             const unsigned d = s_next;
             if (d != TASK_NONE) {
                 const int nt = a.nt;
-                const int b = (int)(d & 0xFFFFF), k = (int)((d >> 20) & 31), i = (int)((d >> 25) & 31);
+                const int b = (int)(d & 0x3FFFF), k = (int)((d >> 20) & 31), i = (int)((d >> 25) & 31), rows = (int)((d >> 18) & 3) + 1;
                 const int* prog = a.sync + TASK_SYNC_HDR + (long long)b * TASK_SYNC_STRIDE;
                 if ((d >> 30) == 3) {               // back-substitution: the whole factor and the solved augmented row
                     task_wait(prog, nt, tmo);
@@ -921,9 +921,10 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
                         task_wait(prog + 1 + k, k, tmo);
                         if (MT > 0) task_wait(prog + 1 + nt, k, tmo);
                     }
-                } else {                            // strip(i, k): inv(L_kk) and tile row k (diag(k)), tile row i up to column k - 1
+                } else {                            // strip(i.., k): inv(L_kk) and tile row k (diag(k)), the tile rows up to column k - 1
                     task_wait(prog, k + 1, tmo);
-                    if (i < nt && k > 0) task_wait(prog + 1 + i, k, tmo);
+                    if (i < nt && k > 0)
+                        for (int r = 0; r < rows; ++r) task_wait(prog + 1 + i + r, k, tmo);
                 }
                 if (GP_DBG_ON(a)) s_ready = __builtin_amdgcn_s_memtime();       // producers done (before the acquire)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -934,7 +935,7 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
         __syncthreads();
         const unsigned d = s_desc;
         if (d == TASK_NONE) break;
-        const int b = (int)(d & 0xFFFFF), k = (int)((d >> 20) & 31), i = (int)((d >> 25) & 31);
+        const int b = (int)(d & 0x3FFFF), k = (int)((d >> 20) & 31), i = (int)((d >> 25) & 31), rows = (int)((d >> 18) & 3) + 1;
         const bool is_back = (d >> 30) == 3;
         const bool is_diag = (d >> 30) == 1;
         const bool with_aug = (d >> 30) == 2;       // strip(k + 1, k) also carries the augmented tile (nt, k)
@@ -983,8 +984,11 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
             GemmArgs gl = a.g;
             gl.k1 = k;
             gl.fk = k;
-            strip_item<FUSE_WD, (MT > 0)>(gl, b, i, k, /*no_update=*/i >= a.nt, 8 * k, smem, smem + 2 * OPER_LDS, tid, lane, wave,
-                                          li, lg, lg * LROW + 32 * wave + li, lg * LROW + li, loff, 0, with_aug);
+            // `rows` consecutive tiles of the column, one after the other: they stream the same B panel, and the task's fetch,
+            // acquire and release are paid once
+            for (int r = 0; r < rows; ++r)
+                strip_item<FUSE_WD, (MT > 0)>(gl, b, i + r, k, /*no_update=*/i >= a.nt, 8 * k, smem, smem + 2 * OPER_LDS, tid, lane,
+                                              wave, li, lg, lg * LROW + 32 * wave + li, lg * LROW + li, loff, 0, with_aug && r == 0);
         }
         // publish: every wave's stores have left the CU, then one lane releases and moves the matrix's progress word(s)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -999,7 +1003,10 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
             if (!is_back) {
                 if (GP_FENCE_MODE(a) == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(is_diag ? prog : prog + 1 + i, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (is_diag) __hip_atomic_store(prog, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    for (int r = 0; r < rows; ++r)
+                        __hip_atomic_store(prog + 1 + i + r, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (with_aug) __hip_atomic_store(prog + 1 + a.nt, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (!hit) {                      // this queue has run dry (or had long before): go on with the others

@@ -19,19 +19,20 @@ def _same(a, b):
 
 def _both(gp, c, doT, max_batch=0, group=0, **kw):
     out = []
-    for tiles in (8, 0):                       # persistent launch, one launch per column
+    for tiles in (8, 0):                       # persistent launch (from 2 tiles per side on), one launch per column
         g = cases.gpslc_object(gp, c)
-        g.ctx().set_task_schedule(tiles, group)
+        g.ctx().set_task_schedule(2, tiles, group)
         if max_batch:
             g.ctx().set_tuning(max_batch, 0, 0)
         out.append(gp.predict(g, doT, want_mean_ite=True, **kw))
     return out
 
 
-@pytest.mark.parametrize("n,S,L", [(300, 37, 1), (1024, 70, 1), (1000, 9, 20), (640, 3, 31), (257, 1, 2)])
+@pytest.mark.parametrize("n,S,L", [(300, 37, 1), (1024, 70, 1), (1000, 9, 20), (640, 3, 31), (257, 1, 2), (896, 19, 3), (200, 5, 1)])
 def test_task_launch_equals_the_per_column_schedule_bit_for_bit(gp, n, S, L):
-    """nt = 2 ... 8 tiles per side, 1 / 2 blocks of augmented rows (L = 1, 20, 31), fewer matrices than queues (S = 1, 3:
-    workgroups on the other XCDs take tickets of the queues that hold work)."""
+    """nt = 3 ... 8 tiles per side (odd and even numbers of strips per column: tasks of one and of two tile rows), 1 / 2 blocks
+    of augmented rows (L = 1, 20, 31), fewer matrices than queues (S = 1, 3: workgroups on the other XCDs take tickets of the
+    queues that hold work); MeanITE compares the back-substitution task with launch_backsolve's kernels."""
     c = cases.make_case(n, "UX", False, S=S, seed=n + S)
     doT = np.linspace(-0.5, 0.7, L)
     a, b = _both(gp, c, doT)
@@ -59,7 +60,7 @@ def test_task_launch_draws_and_logpdf_paths(gp):
     outs = []
     for tiles in (8, 0):
         g = cases.gpslc_object(gp, c)
-        g.ctx().set_task_schedule(tiles, 0)
+        g.ctx().set_task_schedule(2, tiles, 0)
         ms, vs, mi, dr = gp.predict(g, [0.1, 0.6], want_mean_ite=True, spp=3, seed=5, want_draws=True)
         outs.append((ms, vs, mi, dr, gp.yLogpdf(g)))
     for x, y in zip(*outs):
@@ -76,7 +77,7 @@ def test_failing_pivot_is_reported_by_the_task_launch(gp, bad):
     infos, per_sample = [], []
     for tiles in (8, 0):
         g = cases.gpslc_object(gp, c)
-        g.ctx().set_task_schedule(tiles, 0)
+        g.ctx().set_task_schedule(2, tiles, 0)
         with pytest.raises(gp.PosDefException) as ei:
             gp.predict(g, [0.3])
         infos.append(ei.value.info)
@@ -90,7 +91,8 @@ def test_set_task_schedule_arguments(gp):
     c = cases.make_case(24, "UX", False, S=2, seed=2)
     g = cases.gpslc_object(gp, c)
     lib, h = g.ctx().lib, g.ctx().h
-    assert lib.gpslc_set_task_schedule(h, 25, 0) == -2
-    assert lib.gpslc_set_task_schedule(h, 8, 5000) == -3
-    assert lib.gpslc_set_task_schedule(h, -1, 0) == 0
-    assert lib.gpslc_set_task_schedule(None, 8, 8) == -1
+    assert lib.gpslc_set_task_schedule(h, 25, 8, 0) == -2
+    assert lib.gpslc_set_task_schedule(h, 2, 25, 0) == -3
+    assert lib.gpslc_set_task_schedule(h, 2, 8, 5000) == -4
+    assert lib.gpslc_set_task_schedule(h, 0, -1, 0) == 0
+    assert lib.gpslc_set_task_schedule(None, 2, 8, 8) == -1
