@@ -689,6 +689,7 @@ struct PredictIO {
     const double* Y = nullptr;       // right-hand side 0 (default: the ctx's Y) and its per-sample stride
     long long y_sstride = 0;
     bool p_shared_u = false;         // the feature block is shared by all samples (u_sstride stays 0)
+    int64_t ens_off = 0, ens_S = 0;  // ens_S > 0: this call's placement in a larger ensemble (else the ctx's, gpslc_set_ensemble)
 };
 
 int auto_batch(gpslc_ctx* c, int64_t S, size_t per_sample_bytes, size_t fixed_bytes) {
@@ -968,7 +969,10 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                         DrawArgs dr{};
                         dr.Lc = Cm; dr.n = n; dr.nt = nt; dr.s0 = s0 + g0; dr.S = io.S; dr.l = l0; dr.lc = lc; dr.L = L;
                         dr.spp = io.spp; dr.mean = meanITE; dr.z = io.z; dr.zgen = zgen; dr.zt = zt; dr.seed = io.seed;
-                        dr.rs0 = dr.s0 + (c->ens_S > 0 ? c->ens_off : 0); dr.rS = c->ens_S > 0 ? c->ens_S : io.S;
+                        {
+                            const int64_t eS = io.ens_S > 0 ? io.ens_S : c->ens_S, eo = io.ens_S > 0 ? io.ens_off : c->ens_off;
+                            dr.rs0 = dr.s0 + (eS > 0 ? eo : 0); dr.rS = eS > 0 ? eS : io.S;
+                        }
                         if (L == 1) {     // the reference tensor directly: n x (S*spp), instance fastest
                             dr.out = io.ite_draws;
                             dr.obase = (long long)n * io.spp * (s0 + g0); dr.osb = (long long)n * io.spp; dr.osl = 0;
@@ -1160,6 +1164,65 @@ void copy_out_large(gpslc_ctx* c, void* dst, const void* src_dev, size_t bytes) 
             catch (...) { memcpy(d + o, b + o, len); }        // no thread to be had: copy this slice here
         }
         memcpy(d, b, std::min(per, cb));
+        for (auto& th : pool) th.join();
+    }
+}
+
+// The same hand-over for a result whose rows are CONTIGUOUS ON THE DEVICE (rows x row_bytes) and `dpitch` bytes apart in the
+// caller's array: a shard's block of an (n x S x L) array of a level sweep — level l of the shard is one run of n S_r doubles
+// at n (s0 + S l) of the caller's array (gpslc_predict_multi).  The device side is DMA'd in 64 MiB chunks as above; the host
+// threads scatter a chunk to its rows.  Small results: one hipMemcpy2D.
+void copy_out_rows(gpslc_ctx* c, void* dst, size_t dpitch, const void* src_dev, size_t row_bytes, size_t rows) {
+    if (rows == 0 || row_bytes == 0) return;
+    if (rows == 1 || dpitch == row_bytes) { copy_out_large(c, dst, src_dev, row_bytes * rows); return; }
+    const size_t bytes = row_bytes * rows;
+    bool plain = bytes < 2 * kBounceBytes;
+    if (!plain) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, dst) == hipSuccess) plain = at.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
+    }
+    if (!plain) {
+        ensure_streams(c);
+        for (int i = 0; i < 2 && !plain; ++i)
+            if (!c->bounce[i]) {
+                void* p = nullptr;
+                if (hipHostMalloc(&p, kBounceBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); plain = true; }
+                else c->bounce[i] = static_cast<char*>(p);
+            }
+    }
+    if (plain) { HC(hipMemcpy2D(dst, dpitch, src_dev, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost)); return; }
+    hipStream_t st = c->streams[0];
+    const size_t nchunk = (bytes + kBounceBytes - 1) / kBounceBytes;
+    const unsigned nthr = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    auto chunk_bytes = [&](size_t k) { return std::min(kBounceBytes, bytes - k * kBounceBytes); };
+    // bytes [o, o + len) of the device block -> their rows of the caller's array
+    auto scatter = [=](const char* b, size_t o, size_t len) {
+        while (len > 0) {
+            const size_t row = o / row_bytes, within = o - row * row_bytes;
+            const size_t m = std::min(len, row_bytes - within);
+            memcpy(static_cast<char*>(dst) + row * dpitch + within, b, m);
+            b += m; o += m; len -= m;
+        }
+    };
+    HC(hipMemcpyAsync(c->bounce[0], src_dev, chunk_bytes(0), hipMemcpyDeviceToHost, st));
+    for (size_t k = 0; k < nchunk; ++k) {
+        HC(hipStreamSynchronize(st));
+        if (k + 1 < nchunk)
+            HC(hipMemcpyAsync(c->bounce[(k + 1) & 1], static_cast<const char*>(src_dev) + (k + 1) * kBounceBytes,
+                              chunk_bytes(k + 1), hipMemcpyDeviceToHost, st));
+        const size_t cb = chunk_bytes(k), o0 = k * kBounceBytes;
+        const char* b = c->bounce[k & 1];
+        const size_t per = ((cb + nthr - 1) / nthr + 4095) & ~size_t(4095);
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; ++t) {
+            const size_t o = (size_t)t * per;
+            if (o >= cb) break;
+            const size_t len = std::min(per, cb - o);
+            try { pool.emplace_back([=]() { scatter(b + o, o0 + o, len); }); }
+            catch (...) { scatter(b + o, o0 + o, len); }
+        }
+        scatter(b, o0, std::min(per, cb));
         for (auto& th : pool) th.join();
     }
 }
@@ -1469,18 +1532,24 @@ int gpslc_process_cov(gpslc_ctx* c, const double* logcov, int64_t n, double scal
     });
 }
 
+// argument checks of gpslc_predict / gpslc_predict_multi; argoff shifts the reported argument number (code AND message) to the
+// caller's own signature (gpslc_predict_multi has two more leading arguments than gpslc_predict: nctx, ctxs)
 static int predict_check(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,
                          const double* tyLS, const double* yScale, const double* yNoise, int32_t L,
-                         const double* doT, int32_t spp, const double* ite_draws) {
-    int rc = check_common(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise);
-    if (rc) return rc;
-    if (L < 1) return bad_arg(c, 9, "L < 1");
-    if (!doT) return bad_arg(c, 10, "doT is NULL");
-    if (ite_draws && spp < 1) return bad_arg(c, 12, "spp < 1 with ite_draws requested");
+                         const double* doT, int32_t spp, const double* ite_draws, int argoff = 0) {
+    if (!c) return -1;
+    if (!c->has_data) { set_err(c, "gpslc_set_data has not been called"); return GPSLC_ERR_NODATA; }
+    if (S < 0) return bad_arg(c, 2 + argoff, "S < 0");
+    if (c->nU > 0 && S > 0 && (!U || !uyLS)) return bad_arg(c, 3 + argoff, "U / uyLS must not be NULL when nU > 0");
+    if (c->nX > 0 && S > 0 && !xyLS) return bad_arg(c, 5 + argoff, "xyLS must not be NULL when nX > 0");
+    if (S > 0 && (!tyLS || !yScale || !yNoise)) return bad_arg(c, 6 + argoff, "tyLS / yScale / yNoise must not be NULL");
+    if (L < 1) return bad_arg(c, 9 + argoff, "L < 1");
+    if (!doT) return bad_arg(c, 10 + argoff, "doT is NULL");
+    if (ite_draws && spp < 1) return bad_arg(c, 12 + argoff, "spp < 1 with ite_draws requested");
     // a placement left over from an earlier, smaller call would make the stream ids (off + s) + S_total * l of this call's last
     // samples collide with the next level's streams: refuse instead of drawing correlated normals
     if (c->ens_S > 0 && c->ens_off + S > c->ens_S)
-        return bad_arg(c, 2, "S exceeds the room gpslc_set_ensemble left: sample_offset + S > S_total");
+        return bad_arg(c, 2 + argoff, "S exceeds the room gpslc_set_ensemble left: sample_offset + S > S_total");
     return 0;
 }
 
@@ -1488,11 +1557,13 @@ static int predict_check(gpslc_ctx* c, int64_t S, const double* U, const double*
 static int predict_dev_inner(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,
                              const double* tyLS, const double* yScale, const double* yNoise, int32_t L,
                              const double* doT, double pred_noise, int32_t spp, uint64_t seed, const double* z,
-                             double* meanSATE, double* varSATE, double* meanITE, double* ite_draws) {
+                             double* meanSATE, double* varSATE, double* meanITE, double* ite_draws,
+                             int64_t ens_off = 0, int64_t ens_S = 0) {
     PredictIO io;
     io.S = S; io.p = SampleParams{U, uyLS, xyLS, tyLS, yScale, yNoise}; io.X = c->dX;
     io.L = L; io.doT = doT; io.pred_noise = pred_noise; io.spp = spp; io.seed = seed; io.z = z;
     io.meanSATE = meanSATE; io.varSATE = varSATE; io.meanITE = meanITE; io.ite_draws = ite_draws;
+    io.ens_off = ens_off; io.ens_S = ens_S;
     io.info = c->io.take<int>((size_t)S);
     run_predict(c, io);
     return first_info(c);
@@ -1512,6 +1583,56 @@ int gpslc_predict_dev(gpslc_ctx* c, int64_t S, const double* U, const double* uy
     });
 }
 
+// Where a host-pointer prediction over the samples [s0, s0 + S) of S_total sits in the caller's arrays (gpslc_predict_multi:
+// one shard; gpslc_predict: s0 = 0, S_total = S).  Per-sample inputs and the outputs are addressed in the caller's FULL
+// arrays: element (s, l) of an S_total x L array at (s0 + s) + S_total l, block (s, l) of an n x S_total x L array at
+// n ((s0 + s) + S_total l); the level-fastest draw tensor keeps a shard's columns contiguous.
+struct HostPlacement {
+    int64_t s0 = 0, S_total = 0;
+    int64_t ens_off = 0, ens_S = 0;     // Philox stream placement of the shard (ens_S > 0), else the ctx's
+};
+
+// gpslc_predict's body: uploads, run_predict, delivery — every level's run of a shard goes from the device straight to its place
+// in the caller's array (no host staging)
+static int predict_host(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS, const double* tyLS,
+                        const double* yScale, const double* yNoise, int32_t L, const double* doT, double pred_noise, int32_t spp,
+                        uint64_t seed, const double* z, double* meanSATE, double* varSATE, double* meanITE, double* ite_draws,
+                        const HostPlacement& pl) {
+    return guarded(c, [&]() {
+        const size_t n = (size_t)c->n;
+        const size_t s0 = (size_t)pl.s0, St = (size_t)pl.S_total;
+        c->io.reset();
+        const double* dU = c->nU ? up(c, U + n * c->nU * s0, n * c->nU * S) : nullptr;
+        const double* duy = c->nU ? up(c, uyLS + (size_t)c->nU * s0, (size_t)c->nU * S) : nullptr;
+        const double* dxy = c->nX ? up(c, xyLS + (size_t)c->nX * s0, (size_t)c->nX * S) : nullptr;
+        const double* dty = up(c, tyLS + s0, S);
+        const double* dys = up(c, yScale + s0, S);
+        const double* dyn = up(c, yNoise + s0, S);
+        const double* ddo = up(c, doT, L);
+        const double* dz = nullptr;
+        if (z && ite_draws) {      // caller's normals n x spp x S_total x L: level l of the shard is one run of n spp S doubles
+            double* d = c->io.take<double>(n * spp * S * L);
+            const size_t run = n * spp * (size_t)S * sizeof(double);
+            HC(hipMemcpy2D(d, run, z + n * spp * s0, n * spp * St * sizeof(double), run, (size_t)L, hipMemcpyHostToDevice));
+            dz = d;
+        }
+        double* oms = meanSATE ? c->io.take<double>((size_t)S * L) : nullptr;
+        double* ovs = varSATE ? c->io.take<double>((size_t)S * L) : nullptr;
+        double* omi = meanITE ? c->io.take<double>(n * S * L) : nullptr;
+        double* odr = ite_draws ? c->io.take<double>((size_t)L * n * S * spp) : nullptr;
+        int st = predict_dev_inner(c, S, dU, duy, dxy, dty, dys, dyn, L, ddo, pred_noise, spp, seed, dz,
+                                   oms, ovs, omi, odr, pl.ens_off, pl.ens_S);
+        if (st < 0) return st;
+        const size_t sb = (size_t)S * sizeof(double);
+        if (meanSATE) HC(hipMemcpy2D(meanSATE + s0, St * sizeof(double), oms, sb, sb, (size_t)L, hipMemcpyDeviceToHost));
+        if (varSATE) HC(hipMemcpy2D(varSATE + s0, St * sizeof(double), ovs, sb, sb, (size_t)L, hipMemcpyDeviceToHost));
+        if (meanITE) copy_out_rows(c, meanITE + n * s0, n * St * sizeof(double), omi, n * sb, (size_t)L);
+        // level-fastest tensor L x n x (S_total spp): a sample's columns are one contiguous run
+        if (ite_draws) copy_out_large(c, ite_draws + (size_t)L * n * spp * s0, odr, sizeof(double) * (size_t)L * n * S * spp);
+        return st;
+    });
+}
+
 int gpslc_predict(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, const double* xyLS,
                   const double* tyLS, const double* yScale, const double* yNoise, int32_t L, const double* doT,
                   double pred_noise, int32_t spp, uint64_t seed, const double* z, double* meanSATE,
@@ -1519,30 +1640,10 @@ int gpslc_predict(gpslc_ctx* c, int64_t S, const double* U, const double* uyLS, 
     int rc = predict_check(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, spp, ite_draws);
     if (rc) return rc;
     if (S == 0) { c->last_info.clear(); return GPSLC_OK; }
-    return guarded(c, [&]() {
-        const size_t n = (size_t)c->n;
-        c->io.reset();
-        const double* dU = c->nU ? up(c, U, n * c->nU * S) : nullptr;
-        const double* duy = c->nU ? up(c, uyLS, (size_t)c->nU * S) : nullptr;
-        const double* dxy = c->nX ? up(c, xyLS, (size_t)c->nX * S) : nullptr;
-        const double* dty = up(c, tyLS, S);
-        const double* dys = up(c, yScale, S);
-        const double* dyn = up(c, yNoise, S);
-        const double* ddo = up(c, doT, L);
-        const double* dz = (z && ite_draws) ? up(c, z, n * spp * S * L) : nullptr;
-        double* oms = meanSATE ? c->io.take<double>((size_t)S * L) : nullptr;
-        double* ovs = varSATE ? c->io.take<double>((size_t)S * L) : nullptr;
-        double* omi = meanITE ? c->io.take<double>(n * S * L) : nullptr;
-        double* odr = ite_draws ? c->io.take<double>((size_t)L * n * S * spp) : nullptr;
-        int st = predict_dev_inner(c, S, dU, duy, dxy, dty, dys, dyn, L, ddo, pred_noise, spp, seed, dz,
-                                   oms, ovs, omi, odr);
-        if (st < 0) return st;
-        if (meanSATE) HC(hipMemcpy(meanSATE, oms, sizeof(double) * S * L, hipMemcpyDeviceToHost));
-        if (varSATE) HC(hipMemcpy(varSATE, ovs, sizeof(double) * S * L, hipMemcpyDeviceToHost));
-        if (meanITE) copy_out_large(c, meanITE, omi, sizeof(double) * (size_t)n * S * L);
-        if (ite_draws) copy_out_large(c, ite_draws, odr, sizeof(double) * (size_t)L * n * S * spp);
-        return st;
-    });
+    HostPlacement pl;
+    pl.S_total = S;
+    return predict_host(c, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, pred_noise, spp, seed, z, meanSATE, varSATE, meanITE,
+                        ite_draws, pl);
 }
 
 int gpslc_shard_range(int64_t S, int32_t nblocks, int32_t k, int64_t* s0, int64_t* s1) {
@@ -1560,7 +1661,10 @@ int gpslc_shard_range(int64_t S, int32_t nblocks, int32_t k, int64_t* s0, int64_
 // The sharded ensemble behind the ABI (the loop src/prediction.jl:30-33 over src/estimation.jl:78-84): contiguous
 // blocks of the posterior-sample index over the contexts, one host thread per context, data replicated (every ctx holds its own
 // copy: gpslc_set_data), no traffic between the devices while they compute.  The "gather" is each device's own device-to-host
-// copy into ITS block of the caller's arrays — nctx PCIe links in parallel, nothing funnels through one GPU.
+// copy into ITS block of the caller's arrays — nctx PCIe links in parallel, nothing funnels through one GPU — and since round 6
+// every level's run of a shard goes from the device (through the ctx's pinned bounce chunks) straight to its place in the
+// caller's array: no per-shard host staging, no second pass over the results.  A shard's ensemble placement travels as a
+// parameter: the contexts' own gpslc_set_ensemble state is read (ctxs[0]'s places the whole call), never written.
 int gpslc_predict_multi(int32_t nctx, gpslc_ctx* const* ctxs, int64_t S, const double* U, const double* uyLS,
                         const double* xyLS, const double* tyLS, const double* yScale, const double* yNoise, int32_t L,
                         const double* doT, double pred_noise, int32_t spp, uint64_t seed, const double* z,
@@ -1576,64 +1680,32 @@ int gpslc_predict_multi(int32_t nctx, gpslc_ctx* const* ctxs, int64_t S, const d
     for (int k = 1; k < nctx; ++k) {
         if (ctxs[k]->n != c0->n || ctxs[k]->nX != c0->nX || ctxs[k]->nU != c0->nU)
             return bad_arg(c0, 2, "the contexts differ in n / nX / nU");
+        // one precision mode per call: a ctx created with GPSLC_FLAG_FP32_KERNEL would silently mix arithmetics across the shards
+        if ((ctxs[k]->flags & GPSLC_FLAG_FP32_KERNEL) != (c0->flags & GPSLC_FLAG_FP32_KERNEL))
+            return bad_arg(c0, 2, "the contexts differ in GPSLC_FLAG_FP32_KERNEL");
         if (!ctxs[k]->has_data) { set_err(c0, "gpslc_set_data has not been called on every ctx"); return GPSLC_ERR_NODATA; }
     }
-    int rc0 = predict_check(c0, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, spp, ite_draws);
-    if (rc0) return rc0 < 0 && rc0 > -100 ? rc0 - 1 : rc0;      // argument numbers of THIS signature (S is #3, ...)
+    // argument numbers of THIS signature, in the code and in the message (S is #3, ...)
+    int rc0 = predict_check(c0, S, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, spp, ite_draws, /*argoff=*/1);
+    if (rc0) return rc0;
     if (S == 0) { for (int k = 0; k < nctx; ++k) ctxs[k]->last_info.clear(); return GPSLC_OK; }
     try {
-        const int64_t n = c0->n, nU = c0->nU, nX = c0->nX;
         // placement of the whole call (ctxs[0]'s, if the caller set one: this call may itself be one node's share)
         const int64_t base_off = c0->ens_S > 0 ? c0->ens_off : 0, total = c0->ens_S > 0 ? c0->ens_S : S;
-        struct Shard {
-            int64_t s0 = 0, Sr = 0;
-            std::vector<double> z, ms, vs, mi;     // staging where the shard's block is not contiguous in the caller's array (L > 1)
-            int rc = 0;
-            int64_t save_off = 0, save_S = 0;
-        };
+        struct Shard { int64_t s0 = 0, Sr = 0; int rc = 0; };
         std::vector<Shard> sh((size_t)nctx);
-        const bool use_z = z && ite_draws;
         for (int k = 0; k < nctx; ++k) {
-            Shard& h = sh[(size_t)k];
             int64_t s1 = 0;
-            (void)gpslc_shard_range(S, nctx, k, &h.s0, &s1);
-            h.Sr = s1 - h.s0;
-            if (h.Sr == 0 || L == 1) continue;
-            if (use_z) {
-                h.z.resize((size_t)(n * spp * h.Sr * L));
-                for (int l = 0; l < L; ++l)
-                    memcpy(h.z.data() + (size_t)(n * spp * h.Sr) * l, z + (size_t)(n * spp) * (size_t)(h.s0 + S * l),
-                           sizeof(double) * (size_t)(n * spp * h.Sr));
-            }
-            if (meanSATE) h.ms.resize((size_t)(h.Sr * L));
-            if (varSATE) h.vs.resize((size_t)(h.Sr * L));
-            if (meanITE) h.mi.resize((size_t)(n * h.Sr * L));
+            (void)gpslc_shard_range(S, nctx, k, &sh[(size_t)k].s0, &s1);
+            sh[(size_t)k].Sr = s1 - sh[(size_t)k].s0;
         }
         auto work = [&](int k) {
             Shard& h = sh[(size_t)k];
             if (h.Sr == 0) { ctxs[k]->last_info.clear(); return; }
-            gpslc_ctx* c = ctxs[k];
-            h.save_off = c->ens_off; h.save_S = c->ens_S;
-            c->ens_off = base_off + h.s0; c->ens_S = total;
-            const bool direct = L == 1;
-            h.rc = gpslc_predict(c, h.Sr, nU ? U + (size_t)(n * nU) * h.s0 : nullptr, nU ? uyLS + (size_t)nU * h.s0 : nullptr,
-                                 nX ? xyLS + (size_t)nX * h.s0 : nullptr, tyLS + h.s0, yScale + h.s0, yNoise + h.s0, L, doT,
-                                 pred_noise, spp, seed,
-                                 !use_z ? nullptr : (direct ? z + (size_t)(n * spp) * h.s0 : h.z.data()),
-                                 !meanSATE ? nullptr : (direct ? meanSATE + h.s0 : h.ms.data()),
-                                 !varSATE ? nullptr : (direct ? varSATE + h.s0 : h.vs.data()),
-                                 !meanITE ? nullptr : (direct ? meanITE + (size_t)n * h.s0 : h.mi.data()),
-                                 // level-fastest tensor L x n x (S spp): a sample's columns are one contiguous run
-                                 !ite_draws ? nullptr : ite_draws + (size_t)L * n * spp * h.s0);
-            c->ens_off = h.save_off; c->ens_S = h.save_S;
-            if (h.rc >= 0 && !direct) {         // this shard's rows of the S x L and n x S x L arrays
-                for (int l = 0; l < L; ++l) {
-                    if (meanSATE) memcpy(meanSATE + h.s0 + S * l, h.ms.data() + h.Sr * l, sizeof(double) * h.Sr);
-                    if (varSATE) memcpy(varSATE + h.s0 + S * l, h.vs.data() + h.Sr * l, sizeof(double) * h.Sr);
-                    if (meanITE) memcpy(meanITE + (size_t)n * (size_t)(h.s0 + S * l), h.mi.data() + (size_t)(n * h.Sr) * l,
-                                        sizeof(double) * (size_t)(n * h.Sr));
-                }
-            }
+            HostPlacement pl;
+            pl.s0 = h.s0; pl.S_total = S; pl.ens_off = base_off + h.s0; pl.ens_S = total;
+            h.rc = predict_host(ctxs[k], h.Sr, U, uyLS, xyLS, tyLS, yScale, yNoise, L, doT, pred_noise, spp, seed, z, meanSATE,
+                                varSATE, meanITE, ite_draws, pl);
         };
         std::vector<std::thread> pool;
         for (int k = 1; k < nctx; ++k) {
@@ -1658,7 +1730,7 @@ int gpslc_predict_multi(int32_t nctx, gpslc_ctx* const* ctxs, int64_t S, const d
             }
         return rc;
     } catch (const std::bad_alloc&) {
-        set_err(c0, "host staging allocation failed");
+        set_err(c0, "host allocation failed");
         return GPSLC_ERR_NOMEM;
     } catch (...) {
         set_err(c0, "internal error");

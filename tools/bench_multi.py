@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""gpslc_predict_multi (the sharded ensemble behind the C ABI: the loop src/prediction.jl:30-33 over src/estimation.jl:78-84)
+timed against gpslc_predict with everything delivered to HOST arrays — what a Julia caller of the shim sees.
+
+    python3 tools/bench_multi.py [--n 4096 --d 8 --nu 2 --samples 1024 --levels 64 --spp 10 --draw-samples 64]
+
+Two shapes: (a) BASELINE configs[3]'s per-GPU share — S posterior samples x L levels, MeanITE (n x S x L) to the host; (b) L = 1 with
+the draw tensor (n x S spp).  For each: gpslc_predict_dev (compute only, results left in HBM), gpslc_predict (one context, delivery
+included), gpslc_predict_multi with devices [0] and [0, 0] (the pool's boxes have one GPU: two contexts share it, so [0, 0] shows the
+entry point's overhead, not a speed-up).  Prints one JSON object; `delivery_s` = host call minus the compute-only call."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(n, D, K, S, L, spp, draws, mean_ite, reps=2):
+    import torch
+    import causalgpslc_jl_amd as gp
+    from causalgpslc_jl_amd import synth
+    X, T, Y, obj = synth.make_dataset(n, D)
+    post = synth.make_posterior(n, D, K, S, obj, seed=7)
+    doT = synth.levels(T, L)
+    g = gp.GPSLCObject(X, T, Y, post["U"], post["uyLS"], post["xyLS"], post["tyLS"], post["yNoise"], post["yScale"])
+    ctx = g.ctx()
+    lib = ctx.lib
+    ms, vs = np.empty((S, L), order="F"), np.empty((S, L), order="F")
+    mi = np.empty((n, S, L), order="F") if mean_ite else None
+    dr = np.empty((L, n, S * spp), order="F") if draws else None
+
+    def p(x):
+        return None if x is None else C.c_void_p(x.ctypes.data)
+
+    def host_single():
+        ctx.check(lib.gpslc_predict(ctx.h, S, *g._params(), L, p(doT), 1e-10, spp if draws else 0, 5, None, p(ms), p(vs), p(mi), p(dr)))
+
+    def host_multi(devs):
+        cs = g.ctxs(devs)
+        hs = (C.c_void_p * len(cs))(*[c.h for c in cs])
+
+        def f():
+            ctx.check(lib.gpslc_predict_multi(len(cs), hs, S, *g._params(), L, p(doT), 1e-10, spp if draws else 0, 5, None,
+                                              p(ms), p(vs), p(mi), p(dr), None))
+        return f
+
+    # compute only: inputs and outputs resident in HBM
+    dev = torch.device("cuda:0")
+
+    def to_dev(x):
+        return None if x is None else torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, order="F"))).to(dev)
+    packs = [to_dev(post[k]) for k in ("U", "uyLS", "xyLS", "tyLS", "yScale", "yNoise")]
+    ddo = to_dev(doT)
+    dms = torch.empty(S * L, dtype=torch.float64, device=dev)
+    dvs = torch.empty(S * L, dtype=torch.float64, device=dev)
+    dmi = torch.empty(n * S * L, dtype=torch.float64, device=dev) if mean_ite else None
+    ddr = torch.empty(L * n * S * spp, dtype=torch.float64, device=dev) if draws else None
+
+    def tp(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def dev_only():
+        ctx.check(lib.gpslc_predict_dev(ctx.h, S, *[tp(t) for t in packs], L, tp(ddo), 1e-10, spp if draws else 0, 5, None,
+                                        tp(dms), tp(dvs), tp(dmi), tp(ddr)))
+        torch.cuda.synchronize()
+
+    def timed(f):
+        f()
+        best = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            f()
+            best = min(best, time.perf_counter() - t0)
+        return best
+    out = {"shape": {"n": n, "D": D, "nU": K, "S": S, "L": L, "spp": spp if draws else 0, "mean_ite_to_host": bool(mean_ite),
+                     "draws_to_host": bool(draws),
+                     "host_bytes": int((mi.nbytes if mi is not None else 0) + (dr.nbytes if dr is not None else 0) + 2 * ms.nbytes)}}
+    t_dev = timed(dev_only)
+    ref = None
+    for name, f in (("gpslc_predict", host_single), ("gpslc_predict_multi[0]", host_multi([0])),
+                    ("gpslc_predict_multi[0,0]", host_multi([0, 0]))):
+        t = timed(f)
+        cur = [a.copy() for a in (ms, vs, mi, dr) if a is not None]
+        if ref is None:
+            ref = cur
+        same = all(np.array_equal(a, b) for a, b in zip(ref, cur))
+        out[name] = {"call_s": t, "delivery_s": t - t_dev, "over_one_context_call": None, "bit_identical_to_gpslc_predict": bool(same)}
+    if L > 1 and mean_ite:
+        # what round 5's gpslc_predict_multi did for a level sweep, restated with the same calls: per shard a zero-initialised host
+        # staging vector per output (std::vector), gpslc_predict into it, then a level-by-level memcpy into the caller's arrays
+        def r05_style():
+            sms, svs = np.full((S, L), 0.0, order="F"), np.full((S, L), 0.0, order="F")
+            smi = np.full((n, S, L), 0.0, order="F")
+            ctx.check(lib.gpslc_predict(ctx.h, S, *g._params(), L, p(doT), 1e-10, 0, 5, None, p(sms), p(svs), p(smi), None))
+            for l in range(L):
+                ms[:, l] = sms[:, l]
+                vs[:, l] = svs[:, l]
+                mi[:, :, l] = smi[:, :, l]
+        t = timed(r05_style)
+        out["round5_staging_restated"] = {"call_s": t, "delivery_s": t - t_dev, "over_one_context_call": None,
+                                          "bit_identical_to_gpslc_predict": bool(np.array_equal(mi, ref[2]))}
+    base = out["gpslc_predict"]["call_s"]
+    for k in ("gpslc_predict_multi[0]", "gpslc_predict_multi[0,0]", "round5_staging_restated"):
+        if k in out:
+            out[k]["over_one_context_call"] = out[k]["call_s"] / base - 1.0
+    out["compute_only_s"] = t_dev
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--nu", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=1024)
+    ap.add_argument("--levels", type=int, default=64)
+    ap.add_argument("--spp", type=int, default=10)
+    ap.add_argument("--draw-samples", type=int, default=64)
+    a = ap.parse_args()
+    res = {"config4_share": run(a.n, a.d, a.nu, a.samples, a.levels, 0, False, True),
+           "draw_tensor": run(a.n, a.d, a.nu, a.draw_samples, 1, a.spp, True, True)}
+    print(json.dumps(res))
