@@ -87,6 +87,7 @@ def parse():
     ap.add_argument("--config4-levels", type=int, default=64)
     ap.add_argument("--config4-steps", type=int, default=2)
     ap.add_argument("--no-configs", action="store_true", help="skip the short timed runs of BASELINE configs[1] and configs[4]")
+    ap.add_argument("--no-multi-abi", action="store_true", help="skip the timing of gpslc_predict_multi's host delivery")
     ap.add_argument("--binary-t", action="store_true", help="Bernoulli(0.5) treatments (BASELINE config 5 shape)")
     ap.add_argument("--fp32-kernel", action="store_true", help="mixed precision: RBF evaluation in fp32 (config 5)")
     ap.add_argument("--diag-lib", action="store_true",
@@ -891,6 +892,18 @@ def main():
                                  "fp32 kernel build + fp64 Cholesky, unit A with MeanITE, doT=1, 64 posterior samples per step",
                                  literal_golden=os.path.join(ROOT, "tests", "golden", "config5_literal.npz")),
             }
+            if not a.no_multi_abi:
+                # the multi-GPU entry a Julia caller uses (gpslc_predict_multi), everything delivered to host arrays: seconds
+                # of compute against seconds of delivery at BASELINE configs[3]'s per-GPU share (tools/bench_multi.py)
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_multi
+                out["multi_abi"] = {
+                    "what": "gpslc_predict / gpslc_predict_multi (devices [0] and [0, 0]: the pool's boxes have ONE GPU, so the "
+                            "second row pair prices the entry point, not a speed-up) with every output delivered to HOST arrays, "
+                            "best of 2 calls after a warm-up; delivery_s = call - compute-only gpslc_predict_dev; "
+                            "round5_staging_restated = the per-shard std::vector staging round 5 used, restated with the same calls",
+                    "config4_share": bench_multi.run(4096, 8, 2, 1024, 64, 0, False, True),
+                    "draw_tensor": bench_multi.run(4096, 8, 2, 64, 1, 10, True, True)}
             for cfg in out["configs"].values():
                 if not cfg["parity"]["ok"]:
                     rc = 4

@@ -3,6 +3,7 @@
 // a status code); every HIP error is reported through gpslc_last_error.
 #include "../../include/gpslc_hip.h"
 #include "gpslc_internal.h"
+#include "batch_plan.h"
 
 #include <algorithm>
 #include <cmath>
@@ -692,7 +693,9 @@ struct PredictIO {
     int64_t ens_off = 0, ens_S = 0;  // ens_S > 0: this call's placement in a larger ensemble (else the ctx's, gpslc_set_ensemble)
 };
 
-int auto_batch(gpslc_ctx* c, int64_t S, size_t per_sample_bytes, size_t fixed_bytes) {
+// chunk and unit-B sub-batch sizes of a call (batch_plan.h holds the arithmetic; here: what the schedule would like and what
+// the device has)
+BatchPlan auto_batch(gpslc_ctx* c, int64_t S, int L, size_t per_sample_bytes, long long want_bb, size_t unit_bytes, size_t lvl_extra) {
     // enough matrices in flight that the per-step diagonal-block kernel (one workgroup per matrix) and the
     // launch quantisation of the late, small trailing updates are amortised: 1024 at N = 4096 (82 GB of the
     // 288 GB; measured 2013 / 2040 / 2055 / 2064 samples/s at batch 256 / 512 / 1024 / 2048)
@@ -708,13 +711,10 @@ int auto_batch(gpslc_ctx* c, int64_t S, size_t per_sample_bytes, size_t fixed_by
     // the AUTOMATIC chunk also stays under 30 % of the device's memory (arenas never shrink, and the host process usually
     // shares the device: torch's caching allocator under sharded.py / bench.py, other contexts of gpslc_predict_multi on one
     // GPU); 1,024 matrices at N = 4096 are 28 %.  gpslc_set_tuning(max_batch) may ask for more: then only what is free counts.
-    double budget = 0.70 * ((double)free_b + (double)have) / c->nstreams - (double)fixed_bytes;
-    if (c->max_batch <= 0) budget = std::min(budget, 0.30 * (double)tot_b / c->nstreams - (double)fixed_bytes);
-    long long cap = (long long)(budget / (double)per_sample_bytes);
-    if (cap < 1) throw std::bad_alloc();
-    b = std::min(b, cap);
-    b = std::min<long long>(b, S);
-    return (int)std::max<long long>(1, b);
+    const BatchPlan p = plan_batch(b, want_bb, S, L, per_sample_bytes, unit_bytes, lvl_extra, free_b, have, tot_b, c->nstreams,
+                                   c->max_batch <= 0);
+    if (!p.ok) throw std::bad_alloc();
+    return p;
 }
 
 // the chunked ensemble driver (device pointers everywhere)
@@ -769,12 +769,12 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
     const size_t draws_per = want_draws ? ((zimage ? zimage_doubles * 8 + 256 : (io.z ? 0 : (size_t)io.spp * n * 8 + 256)) +
                                            (L > 1 ? (size_t)io.spp * n * 8 + 256 : 0)) : 0;
     const size_t unitB_all = unitB_per + draws_per;
-    const size_t dtmp_extra = (want_draws && L > Bb_target) ? (size_t)(L - Bb_target) * io.spp * n * 8 : 0;
-    const size_t fixed = (size_t)Bb_target * unitB_all + dtmp_extra + (1 << 20);
-    const int Bt = auto_batch(c, io.S, per, fixed);
-    // (sample, level) pairs per unit-B sub-batch: no more than the call has
-    const int Bb = unitB ? (int)std::min<long long>(Bb_target, (long long)Bt * std::max(L, 1)) : 0;
-    const size_t need = (size_t)Bt * per + (size_t)Bb * unitB_all + dtmp_extra + (1 << 20);
+    // chunk size and sub-batch from what the device has (the sub-batch's workspace is sized from the pairs the call
+    // really has, and the 30 % rule of the automatic chunk covers its per-sample part only)
+    const BatchPlan plan = auto_batch(c, io.S, L, per, Bb_target, unitB_all, want_draws ? (size_t)io.spp * n * 8 : 0);
+    const int Bt = (int)plan.Bt;
+    const int Bb = (int)plan.Bb;      // (sample, level) pairs per unit-B sub-batch: no more than the call has
+    const size_t need = (size_t)Bt * per + plan.fixed;
     for (int i = 0; i < c->nstreams; ++i) arena_reserve(c, c->arenas[i], need);
 
     // internal MeanITE buffer when the caller did not ask for it but the draws need it

@@ -42,13 +42,18 @@ def run(n, D, K, S, L, spp, draws, mean_ite, reps=2):
         ctx.check(lib.gpslc_predict(ctx.h, S, *g._params(), L, p(doT), 1e-10, spp if draws else 0, 5, None, p(ms), p(vs), p(mi), p(dr)))
 
     def host_multi(devs):
-        cs = g.ctxs(devs)
-        hs = (C.c_void_p * len(cs))(*[c.h for c in cs])
-
         def f():
+            cs = g.ctxs(devs)
+            hs = (C.c_void_p * len(cs))(*[c.h for c in cs])
             ctx.check(lib.gpslc_predict_multi(len(cs), hs, S, *g._params(), L, p(doT), 1e-10, spp if draws else 0, 5, None,
                                               p(ms), p(vs), p(mi), p(dr), None))
         return f
+
+    def drop_multi():        # the shard contexts keep their workspace (tens of GB each): release them between the variants
+        for cs in g.__dict__.get("_multi", {}).values():
+            for c in cs:
+                c.close()
+        g.__dict__["_multi"] = {}
 
     # compute only: inputs and outputs resident in HBM
     dev = torch.device("cuda:0")
@@ -86,6 +91,7 @@ def run(n, D, K, S, L, spp, draws, mean_ite, reps=2):
     for name, f in (("gpslc_predict", host_single), ("gpslc_predict_multi[0]", host_multi([0])),
                     ("gpslc_predict_multi[0,0]", host_multi([0, 0]))):
         t = timed(f)
+        drop_multi()
         cur = [a.copy() for a in (ms, vs, mi, dr) if a is not None]
         if ref is None:
             ref = cur
@@ -110,6 +116,10 @@ def run(n, D, K, S, L, spp, draws, mean_ite, reps=2):
         if k in out:
             out[k]["over_one_context_call"] = out[k]["call_s"] / base - 1.0
     out["compute_only_s"] = t_dev
+    ctx.close()
+    g._ctx = None
+    del packs, ddo, dms, dvs, dmi, ddr
+    torch.cuda.empty_cache()
     return out
 
 
