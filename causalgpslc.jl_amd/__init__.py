@@ -9,7 +9,7 @@ from .api import (  # noqa: F401
     Context, GPSLCObject, HyperParameters, PREDICTION_COVARIANCE_NOISE,
     rbfKernelLog, rbfKernelLogScalar, logit, expit, processCov, likelihoodDistribution, extractParameters, conditionalITE, ITEDistributions, ITEsamples, conditionalSATE,
     SATEDistributions, SATEsamples, sampleITE, sampleSATE, predictCounterfactualEffects,
-    summarizeEstimates, yLogpdf, gpLogpdf, nodesLogpdf, nodesDraw, mvnLogpdf, predict, doTRange, getN, getNX, getNU, getNumPosteriorSamples,
+    summarizeEstimates, yLogpdf, gpLogpdf, nodesLogpdf, nodesDraw, mvnLogpdf, mvnDraw, predict, doTRange, getN, getNX, getNU, getNumPosteriorSamples,
 )
 from . import synth  # noqa: F401
 from .pack import saveGPSLCObject, loadGPSLCObject, readPackHeader  # noqa: F401

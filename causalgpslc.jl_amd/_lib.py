@@ -64,6 +64,7 @@ SIGNATURES = {
     "gpslc_nodes_logpdf": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, _D]),
     "gpslc_nodes_draw": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, _D, _D]),
     "gpslc_mvn_logpdf": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D]),
+    "gpslc_mvn_draw": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D]),
     "gpslc_predict": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D, _D, _D, C.c_int32, _D, C.c_double,
                                 C.c_int32, C.c_uint64, _D, _D, _D, _D, _D]),
     "gpslc_predict_dev": (C.c_int, [C.c_void_p, C.c_int64, _D, _D, _D, _D, _D, _D, C.c_int32, _D, C.c_double,

@@ -477,6 +477,26 @@ def predictCounterfactualEffects(g: GPSLCObject, nSamplesPerMixture, fidelity=10
     return dr, rng
 
 
+def mvnDraw(cov, z, covscale=None, ctx: Optional[Context] = None):
+    """chol(covscale_s * cov) z_s per column of ``z`` (gpslc_mvn_draw): Gen's `mvnormal(zeros(n), uCov)` — the auxiliary vector
+    of `elliptical_slice(trace, :U => k => :U, zeros(n), uCov)` (src/inference.jl:48-54) and the prior draw of
+    generateUfromSigmaU (src/model_likelihood.jl:4-10) — with the host's normals.  ``cov=None`` re-uses the covariance cached in
+    ``ctx`` (mvnLogpdf caches SigmaU once per data set)."""
+    z = _f(z)
+    if z.ndim == 1:
+        z = z[:, None]
+    n, S = z.shape
+    covf = None
+    if cov is not None:
+        cov = np.asarray(cov, dtype=np.float64)
+        covf = cov if cov.flags.f_contiguous or cov.flags.c_contiguous else np.ascontiguousarray(cov)  # symmetric
+    cs = None if covscale is None else np.ascontiguousarray(np.atleast_1d(covscale), dtype=np.float64)
+    ctx = ctx or Context(n, 0, 0)
+    out = np.empty((n, S), order="F")
+    ctx.check(ctx.lib.gpslc_mvn_draw(ctx.h, S, _p(covf), _p(cs), _p(z), _p(out)))
+    return out
+
+
 def summarizeEstimates(samples, credible_interval=0.90):
     """summarizeEstimates(samples; credible_interval=0.90) (src/driver.jl:129-149): Individual, Mean,
     LowerBound, UpperBound per row of the n x m sample matrix, computed on the GPU (Julia's type-7 quantile: in-LDS
@@ -601,7 +621,8 @@ def nodesDraw(nodes, ctx: Context):
     """Draws from the nodes' Gaussian priors (gpslc_nodes_draw): ``nodes`` as for nodesLogpdf, with standard normals z
     in the target slot; returns chol(K) z per node as the columns of an (n, len(nodes)) array — the `mvnormal(zeros(n),
     cov)` of an elliptical slice's auxiliary vector (src/inference.jl:225-232) or of a prior draw, with the
-    random numbers still drawn on the host.  n <= 640 (GPSLCError -1007 beyond)."""
+    random numbers still drawn on the host (any n: the single-workgroup kernels up to n = 640, the batched tiled
+    factorisation + the predictive-draw kernel beyond)."""
     cnt = len(nodes)
     arr, _keep = _marshal_nodes(nodes, ctx)
     out = np.empty((ctx.n, cnt), order="F")

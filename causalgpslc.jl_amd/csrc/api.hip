@@ -691,6 +691,11 @@ struct PredictIO {
     long long y_sstride = 0;
     bool p_shared_u = false;         // the feature block is shared by all samples (u_sstride stays 0)
     int64_t ens_off = 0, ens_S = 0;  // ens_S > 0: this call's placement in a larger ensemble (else the ctx's, gpslc_set_ensemble)
+    // node draws (gpslc_nodes_draw beyond the single-workgroup kernels): ndraw[:, s] = chol(A_s) nz[:, s] from the batched
+    // tiled factor of A_s (n x S each, device; nzero = n x S zeros, the draw kernel's mean)
+    const double* nz = nullptr;
+    const double* nzero = nullptr;
+    double* ndraw = nullptr;
 };
 
 // chunk and unit-B sub-batch sizes of a call (batch_plan.h holds the arithmetic; here: what the schedule would like and what
@@ -748,6 +753,7 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
                + (size_t)(2 * Np * 8)                // bsum, ksum
                + (size_t)(std::max(L, 1) * 8)        // sumdelta
                + (size_t)(2 * Np * 8)                // zwork + alpha
+               + (size_t)(io.ndraw ? 16 * Np * 8 : 0)   // operand image of the node draw's normals
                + 1024;
     int Bb_target = 0;
     if (unitB) {
@@ -860,6 +866,18 @@ void run_predict(gpslc_ctx* c, const PredictIO& io_in) {
         ea.meanSATE = io.meanSATE; ea.varSATE = io.varSATE; ea.logdet = io.logdet; ea.quad = io.quad;
         ea.from_rows = epi_rows ? 1 : 0;
         launch_epilogue(ea, nb, st);
+
+        if (io.ndraw) {
+            // one draw from N(0, A_s) per parameter set with the caller's normals: L_s z_s on the factor just computed —
+            // Gen's mvnormal(zeros(n), cov) of an elliptical slice's auxiliary vector (src/inference.jl:225-232) and of the
+            // :logitT prior draw (src/model_likelihood.jl:25-33) — the predictive-draw kernel streaming L once
+            double* zt = ar.take<double>((size_t)nb * 16 * Np);
+            DrawArgs dr{};
+            dr.Lc = M; dr.n = n; dr.nt = nt; dr.s0 = s0; dr.S = io.S; dr.l = 0; dr.lc = 1; dr.L = 1; dr.spp = 1;
+            dr.mean = io.nzero; dr.z = io.nz; dr.zt = zt; dr.out = io.ndraw;
+            dr.obase = (long long)n * s0; dr.osb = n; dr.osl = 0; dr.osi = 1; dr.osd = n;
+            launch_draws(dr, nb, st);
+        }
 
         if (want_mean) {
             BackArgs ba{};
@@ -1828,9 +1846,10 @@ int gpslc_y_logpdf(gpslc_ctx* c, int64_t S, const double* U, const double* X_or_
 }
 
 // general (tiled, multi-launch) path of gpslc_gp_logpdf; arguments already validated
+// draws_or_null (host, n x S; needs t_shared == 0): also chol(K_s) target_s — the targets are then standard normals
 static int gp_logpdf_general(gpslc_ctx* c, int64_t S, int32_t nF, const double* F, int32_t f_shared, const double* ls,
                              const double* scale, const double* noise, const double* target, int32_t t_shared,
-                             double* logpdf) {
+                             double* logpdf, double* draws_or_null = nullptr) {
     const size_t n = (size_t)c->n;
     c->io.reset();
     const double* dF = nF ? up(c, F, n * nF * (f_shared ? 1 : S)) : nullptr;
@@ -1851,8 +1870,18 @@ static int gp_logpdf_general(gpslc_ctx* c, int64_t S, int32_t nF, const double* 
     io.X = nullptr; io.nU = nF; io.nX = 0;
     io.Y = dtg; io.y_sstride = t_shared ? 0 : (long long)n;
     io.L = 0; io.doT = ddo; io.logdet = old; io.quad = oq; io.info = c->io.take<int>((size_t)S);
+    double* ddraw = nullptr;
+    if (draws_or_null) {
+        ensure_streams(c);
+        ddraw = c->io.take<double>(n * (size_t)S);
+        double* zero_mean = c->io.take<double>(n * (size_t)S);
+        HC(hipMemsetAsync(zero_mean, 0, n * (size_t)S * sizeof(double), c->streams[0]));
+        HC(hipStreamSynchronize(c->streams[0]));
+        io.nz = dtg; io.nzero = zero_mean; io.ndraw = ddraw;
+    }
     run_predict(c, io);
-    finish_logpdf(c, S, old, oq, logpdf);
+    if (logpdf) finish_logpdf(c, S, old, oq, logpdf);
+    if (draws_or_null) HC(hipMemcpy(draws_or_null, ddraw, n * (size_t)S * sizeof(double), hipMemcpyDeviceToHost));
     return first_info(c);
 }
 
@@ -1885,6 +1914,44 @@ int gpslc_gp_logpdf(gpslc_ctx* c, int64_t S, int32_t nF, const double* F, int32_
     });
 }
 
+// ONE batched pass of the general tiled path over all nodes of a call (S = count parameter sets with per-set feature blocks
+// and per-set targets); draws_or_null: also chol(K_i) target_i per node (gpslc_nodes_draw)
+static int nodes_general(gpslc_ctx* c, int32_t count, const gpslc_node* nodes, int nF_max, double* logpdf, double* draws_or_null) {
+    // Nodes with fewer than nF_max feature columns are padded with zero
+    // columns of lengthscale 1: a padding column adds (0 * 1 - 0 * 1)^2 = +0.0 to every squared distance, so a
+    // node's Gram matrix — and its score — is bit-identical to the one its own feature count would give.
+    // Staging lives in the ctx (this call sits in the MCMC inner loop: no allocation once the buffers have grown),
+    // and nodes that all share ONE feature block — the nX `:X => k => :X` nodes, F = U for every k — hand it over once
+    // (f_shared) instead of count padded copies.
+    const size_t n = (size_t)c->n;
+    bool same_f = true;
+    for (int i = 1; i < count; ++i) same_f = same_f && nodes[i].F == nodes[0].F && nodes[i].nF == nodes[0].nF;
+    std::vector<double>& Fp = c->stage_f;
+    std::vector<double>& rest = c->stage_rest;       // [ls | scale | noise | targets]
+    const size_t ls_n = (size_t)std::max(nF_max, 1) * count;
+    rest.resize(ls_n + 2 * (size_t)count + n * (size_t)count);
+    double* lsp = rest.data();
+    double* sc = lsp + ls_n;
+    double* no = sc + count;
+    double* tg = no + count;
+    std::fill(lsp, lsp + ls_n, 1.0);
+    if (!same_f) {
+        Fp.resize(n * (size_t)nF_max * count);
+        std::fill(Fp.begin(), Fp.end(), 0.0);
+    }
+    for (int i = 0; i < count; ++i) {
+        const gpslc_node& q = nodes[i];
+        if (q.nF > 0) {
+            if (!same_f) memcpy(Fp.data() + (size_t)i * n * nF_max, q.F, n * (size_t)q.nF * sizeof(double));
+            memcpy(lsp + (size_t)i * nF_max, q.ls, (size_t)q.nF * sizeof(double));
+        }
+        sc[i] = q.scale; no[i] = q.noise;
+        memcpy(tg + (size_t)i * n, q.target, n * sizeof(double));
+    }
+    const double* Fsrc = nF_max == 0 ? nullptr : (same_f ? nodes[0].F : Fp.data());
+    return gp_logpdf_general(c, count, nF_max, Fsrc, same_f ? 1 : 0, nF_max ? lsp : nullptr, sc, no, tg, 0, logpdf, draws_or_null);
+}
+
 int gpslc_nodes_logpdf(gpslc_ctx* c, int32_t count, const gpslc_node* nodes, double* logpdf) {
     if (!c) return -1;
     if (count < 0) return bad_arg(c, 2, "count < 0");
@@ -1910,40 +1977,7 @@ int gpslc_nodes_logpdf(gpslc_ctx* c, int32_t count, const gpslc_node* nodes, dou
             }
             return small_nodes_logpdf(c, count, hn.data(), logpdf);
         }
-        // larger n: ONE batched pass of the general tiled path over all nodes (S = count parameter sets with per-set
-        // feature blocks and per-set targets).  Nodes with fewer than nF_max feature columns are padded with zero
-        // columns of lengthscale 1: a padding column adds (0 * 1 - 0 * 1)^2 = +0.0 to every squared distance, so a
-        // node's Gram matrix — and its score — is bit-identical to the one its own feature count would give.
-        // Staging lives in the ctx (this call sits in the MCMC inner loop: no allocation once the buffers have grown),
-        // and nodes that all share ONE feature block — the nX `:X => k => :X` nodes, F = U for every k — hand it over once
-        // (f_shared) instead of count padded copies.
-        const size_t n = (size_t)c->n;
-        bool same_f = true;
-        for (int i = 1; i < count; ++i) same_f = same_f && nodes[i].F == nodes[0].F && nodes[i].nF == nodes[0].nF;
-        std::vector<double>& Fp = c->stage_f;
-        std::vector<double>& rest = c->stage_rest;       // [ls | scale | noise | targets]
-        const size_t ls_n = (size_t)std::max(nF_max, 1) * count;
-        rest.resize(ls_n + 2 * (size_t)count + n * (size_t)count);
-        double* lsp = rest.data();
-        double* sc = lsp + ls_n;
-        double* no = sc + count;
-        double* tg = no + count;
-        std::fill(lsp, lsp + ls_n, 1.0);
-        if (!same_f) {
-            Fp.resize(n * (size_t)nF_max * count);
-            std::fill(Fp.begin(), Fp.end(), 0.0);
-        }
-        for (int i = 0; i < count; ++i) {
-            const gpslc_node& q = nodes[i];
-            if (q.nF > 0) {
-                if (!same_f) memcpy(Fp.data() + (size_t)i * n * nF_max, q.F, n * (size_t)q.nF * sizeof(double));
-                memcpy(lsp + (size_t)i * nF_max, q.ls, (size_t)q.nF * sizeof(double));
-            }
-            sc[i] = q.scale; no[i] = q.noise;
-            memcpy(tg + (size_t)i * n, q.target, n * sizeof(double));
-        }
-        const double* Fsrc = nF_max == 0 ? nullptr : (same_f ? nodes[0].F : Fp.data());
-        return gp_logpdf_general(c, count, nF_max, Fsrc, same_f ? 1 : 0, nF_max ? lsp : nullptr, sc, no, tg, 0, logpdf);
+        return nodes_general(c, count, nodes, nF_max, logpdf, nullptr);
     });
 }
 
@@ -1960,24 +1994,64 @@ int gpslc_nodes_draw(gpslc_ctx* c, int32_t count, const gpslc_node* nodes, doubl
         nF_max = std::max(nF_max, (int)q.nF);
     }
     if (count == 0) { c->last_info.clear(); return GPSLC_OK; }
-    if (!fast_path_ok(c, nF_max, count)) {
-        c->err = "gpslc_nodes_draw: only the single-workgroup node kernels keep the whole factor (n <= 640, fp64 kernel, count <= 512)";
-        return GPSLC_ERR_UNSUPPORTED;
-    }
     return guarded(c, [&]() {
-        std::vector<HostNode> hn((size_t)count);
-        for (int i = 0; i < count; ++i) {
-            HostNode& h = hn[i];
-            h = HostNode{};
-            h.nF = nodes[i].nF;
-            h.F[0] = nodes[i].F; h.nFpart[0] = nodes[i].nF; h.ls[0] = nodes[i].ls;
-            h.scale = nodes[i].scale; h.noise = nodes[i].noise; h.target = nodes[i].target;
-        }
         std::vector<double> lp((size_t)count);
-        const int st = small_nodes_logpdf(c, count, hn.data(), lp.data(), draws);
+        int st;
+        if (fast_path_ok(c, nF_max, count)) {
+            std::vector<HostNode> hn((size_t)count);
+            for (int i = 0; i < count; ++i) {
+                HostNode& h = hn[i];
+                h = HostNode{};
+                h.nF = nodes[i].nF;
+                h.F[0] = nodes[i].F; h.nFpart[0] = nodes[i].nF; h.ls[0] = nodes[i].ls;
+                h.scale = nodes[i].scale; h.noise = nodes[i].noise; h.target = nodes[i].target;
+            }
+            st = small_nodes_logpdf(c, count, hn.data(), lp.data(), draws);
+        } else {
+            // beyond the single-workgroup kernels (n > 640, many nodes, fp32 kernel mode): the batched tiled factorisation of
+            // every node's covariance, then L z on the predictive-draw kernel (round 6)
+            st = nodes_general(c, count, nodes, nF_max, lp.data(), draws);
+        }
         if (logpdf_or_null) memcpy(logpdf_or_null, lp.data(), (size_t)count * sizeof(double));
         return st;
     });
+}
+
+// caches the dense covariance (small n: every evaluation refactorises it in LDS) or its tiled factor (substitution-based:
+// SigmaU * uNoise is near-singular by construction, 1e-13 jitter, src/utils.jl:17-33) in the context; mvn_info = its LAPACK-style info
+static void mvn_cache(gpslc_ctx* c, const double* cov, bool small) {
+    const size_t n = (size_t)c->n;
+    c->mvn_valid = false;
+    if (small) {
+        if (!c->mvn_dense) HC(hipMalloc((void**)&c->mvn_dense, n * n * sizeof(double)));
+        HC(hipMemcpy(c->mvn_dense, cov, n * n * sizeof(double), hipMemcpyHostToDevice));
+        // validate once (as the general path does when it caches the factor): info of cov itself
+        std::vector<double> zeros(n, 0.0);
+        HostNode probe{};
+        probe.dev_cov = c->mvn_dense; probe.covscale = 1.0; probe.target = zeros.data();
+        double dummy = 0.0;
+        c->mvn_info = small_nodes_logpdf(c, 1, &probe, &dummy);
+        c->mvn_valid = true;
+        return;
+    }
+    ensure_streams(c);
+    const int nt = c->nt;
+    const long long nlow = (long long)nt * (nt + 1) / 2;
+    hipStream_t st = c->streams[0];
+    if (!c->mvn_tiles) HC(hipMalloc((void**)&c->mvn_tiles, (size_t)nlow * GP_TSQ * 8));
+    DevBuf bcov, old, oq, info;
+    const double* dcov = up(bcov, cov, n * n);
+    old.alloc(8); oq.alloc(8); info.alloc(sizeof(int));
+    HC(hipMemsetAsync(info.p, 0, sizeof(int), st));
+    TRef M = lower_ref(c->mvn_tiles, nlow * GP_TSQ);
+    launch_dense_load(DenseLoadArgs{dcov, (int)n, nt, M}, st);
+    potrf_tiles(c, M, nt, nt, nullptr, 0, info.as<int>(), 0, 1, st, 0, 0, /*robust=*/true);
+    launch_quad_rows(QuadRowsArgs{M, (int)n, nt, 0, 0, old.as<double>(), oq.as<double>()}, st);
+    HC(hipStreamSynchronize(st));
+    HC(hipGetLastError());
+    HC(hipMemcpy(&c->mvn_logdet, old.p, 8, hipMemcpyDeviceToHost));
+    HC(hipMemcpy(&c->mvn_info, info.p, sizeof(int), hipMemcpyDeviceToHost));
+    c->mvn_valid = true;
 }
 
 int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* covscale, const double* x,
@@ -1992,18 +2066,8 @@ int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* c
         // and solves in LDS (k_small.hip) — cheaper than the tiled forward solve against a cached factor
         return guarded(c, [&]() {
             const size_t n = (size_t)c->n;
-            if (cov) {
-                c->mvn_valid = false;
-                if (!c->mvn_dense) HC(hipMalloc((void**)&c->mvn_dense, n * n * sizeof(double)));
-                HC(hipMemcpy(c->mvn_dense, cov, n * n * sizeof(double), hipMemcpyHostToDevice));
-                // validate once (as the general path does when it caches the factor): info of cov itself
-                std::vector<double> zeros(n, 0.0);
-                HostNode probe{};
-                probe.dev_cov = c->mvn_dense; probe.covscale = 1.0; probe.target = zeros.data();
-                double dummy = 0.0;
-                c->mvn_info = small_nodes_logpdf(c, 1, &probe, &dummy);
-                c->mvn_valid = true;
-            }
+            if (cov) mvn_cache(c, cov, true);
+            else if (!c->mvn_dense) return bad_arg(c, 3, "cov is NULL and the cached factor belongs to the tiled path (S > 512 earlier)");
             c->last_info.assign((size_t)S, c->mvn_info);
             if (S == 0 || c->mvn_info != 0) {
                 for (int64_t s = 0; s < S; ++s) logpdf[s] = NAN;
@@ -2026,24 +2090,8 @@ int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* c
         const int n = (int)c->n, nt = c->nt;
         const long long nlow = (long long)nt * (nt + 1) / 2;
         hipStream_t st = c->streams[0];
-        if (cov) {   // factor once, keep L and the inverted diagonal blocks in the context
-            c->mvn_valid = false;
-            if (!c->mvn_tiles) HC(hipMalloc((void**)&c->mvn_tiles, (size_t)nlow * GP_TSQ * 8));
-            DevBuf bcov, old, oq, info;
-            const double* dcov = up(bcov, cov, (size_t)n * n);
-            old.alloc(8); oq.alloc(8); info.alloc(sizeof(int));
-            HC(hipMemsetAsync(info.p, 0, sizeof(int), st));
-            TRef M = lower_ref(c->mvn_tiles, nlow * GP_TSQ);
-            launch_dense_load(DenseLoadArgs{dcov, n, nt, M}, st);
-            // by substitution: SigmaU * uNoise is near-singular by construction (1e-13 jitter, src/utils.jl:17-33)
-            potrf_tiles(c, M, nt, nt, nullptr, 0, info.as<int>(), 0, 1, st, 0, 0, /*robust=*/true);
-            launch_quad_rows(QuadRowsArgs{M, n, nt, 0, 0, old.as<double>(), oq.as<double>()}, st);
-            HC(hipStreamSynchronize(st));
-            HC(hipGetLastError());
-            HC(hipMemcpy(&c->mvn_logdet, old.p, 8, hipMemcpyDeviceToHost));
-            HC(hipMemcpy(&c->mvn_info, info.p, sizeof(int), hipMemcpyDeviceToHost));
-            c->mvn_valid = true;
-        }
+        if (cov) mvn_cache(c, cov, false);   // factor once, keep L in the context
+        else if (!c->mvn_tiles) return bad_arg(c, 3, "cov is NULL and no tiled factor is cached");
         c->last_info.assign((size_t)S, c->mvn_info);
         if (S == 0 || c->mvn_info != 0) {
             for (int64_t s = 0; s < S; ++s) logpdf[s] = NAN;
@@ -2083,6 +2131,65 @@ int gpslc_mvn_logpdf(gpslc_ctx* c, int64_t S, const double* cov, const double* c
             const double sc = covscale ? covscale[s] : 1.0;
             logpdf[s] = -0.5 * ((double)n * l2pi + (double)n * std::log(sc) + c->mvn_logdet + q[s] / sc);
         }
+        return GPSLC_OK;
+    });
+}
+
+// draws[:, s] = chol(covscale_s cov) z[:, s]: Gen's mvnormal(zeros(n), uCov) with the host's normals — the auxiliary vector of
+// elliptical_slice(trace, :U => k => :U, zeros(n), uCov) (src/inference.jl:48-54) and the prior draw generateUfromSigmaU
+// (src/model_likelihood.jl:4-10) — from the covariance gpslc_mvn_logpdf caches (chol(s C) = sqrt(s) chol(C))
+int gpslc_mvn_draw(gpslc_ctx* c, int64_t S, const double* cov, const double* covscale, const double* z, double* draws) {
+    if (!c) return -1;
+    if (S < 0) return bad_arg(c, 2, "S < 0");
+    if (!cov && !c->mvn_valid) return bad_arg(c, 3, "cov is NULL and no factor is cached");
+    if (S > 0 && !z) return bad_arg(c, 5, "z is NULL");
+    if (S > 0 && !draws) return bad_arg(c, 6, "draws is NULL");
+    const bool small = fast_path_ok(c, 0, std::max<int64_t>(S, 1));
+    return guarded(c, [&]() {
+        const size_t n = (size_t)c->n;
+        if (cov) mvn_cache(c, cov, small);
+        else if (small ? !c->mvn_dense : !c->mvn_tiles) return bad_arg(c, 3, "cov is NULL and the cached covariance belongs to the other path");
+        c->last_info.assign((size_t)S, c->mvn_info);
+        if (S == 0) return GPSLC_OK;
+        if (c->mvn_info != 0) {
+            for (size_t e = 0; e < n * (size_t)S; ++e) draws[e] = NAN;
+            return c->mvn_info;
+        }
+        if (small) {
+            std::vector<HostNode> hn((size_t)S);
+            for (int64_t s = 0; s < S; ++s) {
+                hn[s] = HostNode{};
+                hn[s].dev_cov = c->mvn_dense;
+                hn[s].covscale = covscale ? covscale[s] : 1.0;
+                hn[s].target = z + s * n;
+            }
+            std::vector<double> lp((size_t)S);
+            return small_nodes_logpdf(c, (int)S, hn.data(), lp.data(), draws);
+        }
+        // tiled: L z on the predictive-draw kernel (every unit streams the ONE cached factor: batch stride 0), scaled on the host
+        ensure_streams(c);
+        hipStream_t st = c->streams[0];
+        const int nt = c->nt;
+        const long long Np = (long long)nt * GP_TS;
+        c->io.reset();
+        const double* dz = up(c, z, n * (size_t)S);
+        double* zero_mean = c->io.take<double>(n * (size_t)S);
+        double* out = c->io.take<double>(n * (size_t)S);
+        double* zt = c->io.take<double>((size_t)S * 16 * Np);
+        HC(hipMemsetAsync(zero_mean, 0, n * (size_t)S * sizeof(double), st));
+        DrawArgs dr{};
+        dr.Lc = lower_ref(c->mvn_tiles, 0); dr.n = (int)n; dr.nt = nt; dr.s0 = 0; dr.S = S; dr.l = 0; dr.lc = 1; dr.L = 1; dr.spp = 1;
+        dr.mean = zero_mean; dr.z = dz; dr.zt = zt; dr.out = out;
+        dr.obase = 0; dr.osb = (long long)n; dr.osl = 0; dr.osi = 1; dr.osd = (long long)n;
+        launch_draws(dr, (int)S, st);
+        HC(hipStreamSynchronize(st));
+        HC(hipGetLastError());
+        HC(hipMemcpy(draws, out, n * (size_t)S * sizeof(double), hipMemcpyDeviceToHost));
+        if (covscale)
+            for (int64_t s = 0; s < S; ++s) {
+                const double r = std::sqrt(covscale[s]);
+                for (size_t i = 0; i < n; ++i) draws[s * n + i] *= r;
+            }
         return GPSLC_OK;
     });
 }

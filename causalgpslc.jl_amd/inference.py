@@ -166,8 +166,8 @@ class _RealTChain:
         self.ctx = Context(self.n, 0, 0, device=device)
         self.ctx.set_data(None, np.zeros(self.n), np.zeros(self.n))
         if nU:
-            api.mvnLogpdf(SigmaU, np.zeros((self.n, 0)), ctx=self.ctx)    # factor SigmaU once (cached)
-            self.Lsig = np.linalg.cholesky(SigmaU)                        # for the slice's auxiliary draw
+            api.mvnLogpdf(SigmaU, np.zeros((self.n, 0)), ctx=self.ctx)    # SigmaU handed over once (cached in the ctx: scores
+                                                                          # AND the slices' auxiliary draws, _u_draw)
         ig = lambda name: priorparams[name + "Scale"] / rng.gamma(priorparams[name + "Shape"])   # noqa: E731
         # generate(): latent addresses from the prior (src/inference.jl:20, :75); :T, :Y (and :X => k => :X) constrained
         v = {k: ig(k) for k in ("yNoise", "tyLS", "yScale")}
@@ -185,7 +185,7 @@ class _RealTChain:
             for name in ("xNoise", "xScale"):
                 v[name] = np.array([ig(name) for _ in range(self.nX)])
         self.v = v
-        self.U = [math.sqrt(v["uNoise"]) * (self.Lsig @ rng.standard_normal(self.n)) for _ in range(nU)]
+        self.U = [self._u_draw(rng.standard_normal(self.n)) for _ in range(nU)]
         if binary:                        # :logitT from its prior, the :T => i => :T nodes are constrained
             self.logitT = self._t_draw(rng.standard_normal(self.n))
         self.s_u = self.score_u()
@@ -204,26 +204,21 @@ class _RealTChain:
         cols = ([self._umodel(U)] if self.nU else []) + ([self.X] if self.nX else [])
         return np.column_stack(cols), np.concatenate(ls)
 
-    def _t_cov(self):
-        """logitTCov = processCov(utCovLog + xtCovLog, tScale, tNoise) (src/model_likelihood.jl:25-33) on the host
-        — needed as a matrix only to draw the slice's auxiliary vector (src/inference.jl:216-227).  The model's
-        own (interleaved) U is used so that the ellipse is the prior of the node it moves."""
-        F, ls = self._t_features()
-        if not F.shape[1]:
-            return np.eye(self.n)         # generateBinaryTfromPrior, src/model_prior.jl:195-200
-        Fs = F / ls[None, :]
-        sq = np.sum(Fs * Fs, axis=1)
-        d2 = np.maximum(sq[:, None] + sq[None, :] - 2.0 * (Fs @ Fs.T), 0.0)
-        return self.v["tScale"] * np.exp(-d2) + self.v["tNoise"] * np.eye(self.n)
+    def _u_draw(self, z):
+        """chol(SigmaU * uNoise) z — Gen's `mvnormal(zeros(n), uCov)` (generateUfromSigmaU, src/model_likelihood.jl:4-10; the
+        auxiliary vector of the :U => k => :U slices, src/inference.jl:48-54) with the host's normals, from the covariance the
+        ctx caches (gpslc_mvn_draw)."""
+        return api.mvnDraw(None, z, covscale=[self.v["uNoise"]], ctx=self.ctx)[:, 0]
 
     def _t_draw(self, z):
         """chol(logitTCov) z — Gen's `mvnormal(zeros(n), logitTCov)` (src/model_likelihood.jl:25-33; the slice's auxiliary
-        vector, src/inference.jl:225-232) with the host's normals: on the GPU, in the launch that factors the node's
-        covariance (gpslc_nodes_draw), while the node kernels cover n; beyond (n > 640) on the host."""
+        vector, src/inference.jl:225-232) with the host's normals: on the GPU, by the call that factors the node's covariance
+        (gpslc_nodes_draw: one workgroup up to n = 640, the batched tiled factorisation beyond).  Without features the
+        covariance is the identity (generateBinaryTfromPrior, src/model_prior.jl:195-200): the draw is z itself."""
         F, ls = self._t_features()
-        if F.shape[1] and self.n <= 640:
-            return api.nodesDraw([(F, ls, self.v["tScale"], self.v["tNoise"], z)], self.ctx)[:, 0]
-        return np.linalg.cholesky(self._t_cov()) @ z
+        if not F.shape[1]:
+            return np.array(z, dtype=np.float64)
+        return api.nodesDraw([(F, ls, self.v["tScale"], self.v["tNoise"], z)], self.ctx)[:, 0]
 
     def score_b(self, logitT=None):
         """sum_i log bernoulli(T_i; expit(logitT_i)) (generateBinaryT, src/model_prior.jl:21-24) — host scalar work."""
@@ -551,7 +546,7 @@ class _RealTChain:
         of launches (≈ 10 tries per slice on IHDP), not the chain.  ``depth=1`` is the reference's schedule."""
         rng = self.rng
         depth = self.slice_depth if depth is None else depth
-        nu = math.sqrt(self.v["uNoise"]) * (self.Lsig @ rng.standard_normal(self.n))
+        nu = self._u_draw(rng.standard_normal(self.n))
         log_y = float(np.sum(self.s_x)) + self.s_t + self.s_y + math.log(rng.random())
         theta = rng.uniform(0.0, 2.0 * math.pi)
         lo, hi = theta - 2.0 * math.pi, theta

@@ -160,9 +160,10 @@ int gpslc_nodes_logpdf(gpslc_ctx* ctx, int32_t count, const gpslc_node* nodes, d
  * target_i a vector of standard normals supplied by the caller (the host keeps its random-number stream) — what Gen's
  * `mvnormal(zeros(n), cov)` does inside `elliptical_slice(trace, addr, mu, cov)` (src/inference.jl:48-54, 92-98, 232,
  * 348; covariances built at src/inference.jl:225-227, 286-287, 343-344) and inside `generate` for the prior draws.
- * Same single launch as gpslc_nodes_logpdf (the factor never leaves the CU / its L2 scratch); logpdf_or_null, when
- * given, receives log N(target_i; 0, K_i) as a by-product.  n <= 640 and count <= 512 only (GPSLC_ERR_UNSUPPORTED
- * otherwise: the batched tiled path does not keep a whole factor per node).  Return value / gpslc_last_info as above. */
+ * Same single launch as gpslc_nodes_logpdf while the single-workgroup kernels cover the call (n <= 640, count <= 512: the
+ * factor never leaves the CU / its L2 scratch); beyond — larger n, more nodes, the fp32 kernel mode — the batched tiled
+ * factorisation of every node's covariance followed by L z on the predictive-draw kernel (round 6).  logpdf_or_null, when
+ * given, receives log N(target_i; 0, K_i) as a by-product.  Return value / gpslc_last_info as above. */
 int gpslc_nodes_draw(gpslc_ctx* ctx, int32_t count, const gpslc_node* nodes, double* draws /* n x count */,
                      double* logpdf_or_null /* count */);
 
@@ -176,6 +177,15 @@ int gpslc_nodes_draw(gpslc_ctx* ctx, int32_t count, const gpslc_node* nodes, dou
  * inverted blocks), i.e. backward stable like LAPACK's potrf / trsm. */
 int gpslc_mvn_logpdf(gpslc_ctx* ctx, int64_t S, const double* cov, const double* covscale /* S */,
                      const double* x /* n x S */, double* logpdf /* S */);
+
+/* draws[:, s] = chol(covscale_s * cov) z[:, s] for the host's standard normals z: Gen's `mvnormal(zeros(n), uCov)` inside
+ * `elliptical_slice(trace, :U => k => :U, zeros(n), uCov)` (uCov = SigmaU * uNoise, src/inference.jl:48-54, 92-98, 233-239,
+ * 293-299) and the prior draw of generateUfromSigmaU (src/model_likelihood.jl:4-10).  cov as for gpslc_mvn_logpdf: non-NULL =
+ * handed over and cached, NULL = the cached one (the one gpslc_mvn_logpdf holds for the data set's SigmaU); chol(s C) =
+ * sqrt(s) chol(C), so one factor serves every uNoise.  n <= 640: the node kernels' draw mode; beyond: the cached tiled
+ * factor streamed once per vector by the predictive-draw kernel.  Returns 0, the failing pivot of cov, or a negative status. */
+int gpslc_mvn_draw(gpslc_ctx* ctx, int64_t S, const double* cov, const double* covscale /* S */,
+                   const double* z /* n x S */, double* draws /* n x S */);
 
 /* ---- src/estimation.jl, src/driver.jl, src/prediction.jl ------------------------------ */
 

@@ -207,6 +207,19 @@ function mvn_logpdf(c::Ctx, cov, covscale, x)
     out
 end
 
+"""chol(covscale_s * cov) z_s per column of `z`: Gen's `mvnormal(zeros(n), uCov)` of `elliptical_slice(trace, :U => k => :U,
+zeros(n), uCov)` (src/inference.jl:48-54) and of generateUfromSigmaU's prior draw, with the host's normals; `cov = nothing`
+re-uses the covariance `mvn_logpdf` cached."""
+function mvn_draw(c::Ctx, cov, covscale, z)
+    S = size(z, 2)
+    out = Matrix{Float64}(undef, c.n, S)
+    cf, sf, zf = f64(cov), f64(covscale), f64(z)
+    GC.@preserve cf sf zf out check(c, ccall((:gpslc_mvn_draw, lib), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        c.h, S, ptr(cf), ptr(sf), ptr(zf), pointer(out)))
+    out
+end
+
 # ---- the posterior pack: extractParameters stacked for nBurnIn:stepSize:nOuter (src/utils.jl:92-124) ------------
 struct Pack
     U::Union{Array{Float64,3},Nothing}        # n x nU x S
@@ -444,7 +457,7 @@ function gp_score(c::Ctx, F::Matrix{Float64}, ls::Vector{Float64}, scale::Float6
     end
 end
 
-"""chol(scale exp.(rbfKernelLog(F, F, ls)) + noise I) * z for the caller's standard normals z (n <= 640)."""
+"""chol(scale exp.(rbfKernelLog(F, F, ls)) + noise I) * z for the caller's standard normals z (any n)."""
 function draw(c::Ctx, F::Matrix{Float64}, ls::Vector{Float64}, scale::Float64, noise::Float64, z::Vector{Float64})
     size(F, 2) == length(ls) || throw(DimensionMismatch("draw: $(size(F, 2)) feature columns, $(length(ls)) lengthscales"))
     GC.@preserve F ls z begin
@@ -816,11 +829,7 @@ end
 
 function Gen.random(::HipGPNormal, F::Matrix{Float64}, ls::Vector{Float64}, scale::Float64, noise::Float64)
     n = size(F, 1)
-    n <= 640 && return GPSLCHip.draw(GPSLCHip.nctx(n), F, ls, scale, noise, randn(n))
-    # beyond the single-launch node kernels: Gram matrix from the GPU, factor on the host (prior draws are rare: once per
-    # `generate`, src/inference.jl:20)
-    K = processCov(GPSLCHip.rbf_log(GPSLCHip.kctx(), F, F, ls), scale, noise)
-    LinearAlgebra.cholesky(LinearAlgebra.Symmetric(K)).L * randn(n)
+    GPSLCHip.draw(GPSLCHip.nctx(n), F, ls, scale, noise, randn(n))      # any n: gpslc_nodes_draw (tiled path beyond n = 640)
 end
 Gen.has_output_grad(::HipGPNormal) = false
 Gen.has_argument_grads(::HipGPNormal) = ntuple(_ -> false, 4)              # F, ls, scale, noise

