@@ -136,8 +136,8 @@ struct gpslc_ctx {
     std::vector<TaskList> task_lists;
     unsigned long long task_clock = 0;
     bool task_used = false;
-    int task_min_nt = 5, task_max_nt = 8;   // tile counts in this range take the persistent launch (640 <= N <= 1024: below,
-                                            // one launch per column is faster — N = 512: -5 %, profiles/r06_ab_experiments.md)
+    int task_min_nt = 4, task_max_nt = 8;   // tile counts in this range take the persistent launch (384 < N <= 1024; below, one
+                                            // launch per column is faster — N = 384: -6 %, profiles/r06_ab_experiments.md §1)
     int task_group = 8;            // matrices per group of the task order (see build_task_list)
     int task_rows = 2;             // consecutive tile rows of a column per strip task
     Arena scratch;                 // call-level buffers (internal MeanITE of a draws-only call, ...)
@@ -414,6 +414,7 @@ TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstri
 // at the same time on one XCD and share the B panel L(k, 0..k-1) in its L2.
 std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, int rows_per_task, long long* ntasks_out) {
     std::vector<unsigned> out(TASK_LIST_HDR, 0u);
+    static const int merge_diag = diag_env("GPSLC_TASK_MERGE", 1);      // measurement switch: 0 = strip(k + 1, k) as a task of its own
     const int NS = 2 * nt + (back ? 1 : 0);       // back: one more stage, the back-substitution of the finished factor
     long long total = 0;
     const int wq = nb >> 3, wrm = nb & 7;
@@ -429,10 +430,11 @@ std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, int rows_
                 for (int j = g * G; j < std::min(xc, (g + 1) * G); ++j) {
                     const int b = x0 + j;
                     if (s == 2 * nt) { out.push_back(task_pack(b, 0, 0, TASK_BACK)); continue; }
-                    if ((s & 1) == 0) { out.push_back(task_pack(b, k, k, TASK_DIAG)); continue; }
-                    // the strip of tile row k + 1 carries the augmented tile of the column (the next diagonal task waits for
-                    // exactly those two); the last column has no strip: its augmented tile is a task of its own
-                    if (k + 1 < nt) out.push_back(task_pack(b, k, k + 1, TASK_STRIP_AUG));
+                    // a diagonal task goes on with the strip of tile row k + 1 and the augmented tile of its column (rows = 2 in
+                    // its descriptor): the next diagonal task waits for exactly those two.  The last column has no strip: its
+                    // augmented tile is a task of its own
+                    if ((s & 1) == 0) { out.push_back(task_pack(b, k, k, TASK_DIAG, (merge_diag && k + 1 < nt) ? 2 : 1)); continue; }
+                    if (k + 1 < nt) { if (!merge_diag) out.push_back(task_pack(b, k, k + 1, TASK_STRIP_AUG)); }
                     else out.push_back(task_pack(b, k, nt, TASK_STRIP));
                     for (int i = k + 2; i < nt; i += rows_per_task)
                         out.push_back(task_pack(b, k, i, TASK_STRIP, std::min(rows_per_task, nt - i)));

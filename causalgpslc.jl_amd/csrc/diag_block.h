@@ -155,6 +155,14 @@ __device__ __forceinline__ void sb_trail2(double* P, int p, int t, int t2, int n
 // tiles (L_kk, inv(L_kk)) in HBM; image_ready: the lower blocks are already in P (the caller has NOT yet synchronised: the
 // first barrier is in here); a non-positive pivot c (0-based) is reported as info_code0 + c + 1 through an atomicCAS on
 // *info_word.  Called by all 256 threads of the workgroup (it contains barriers).
+// WT (the persistent task launch, potrf_tasks_kernel): the output tiles are stored WRITE-THROUGH (agent-scope relaxed atomic
+// stores = global_store ... sc1), so that another workgroup of the same launch can be handed them without an L2 write-back
+template <bool WT>
+__device__ __forceinline__ void out_store(double* p, double v) {
+    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool WT = false>
 __device__ __forceinline__ void diag_potrf_inv_la_body(double* P, double* tile, double* invt, int* info_word,
                                                        int info_code0, int tid, bool image_ready,
                                                        unsigned long long* stamps = nullptr) {
@@ -175,8 +183,8 @@ __device__ __forceinline__ void diag_potrf_inv_la_body(double* P, double* tile, 
     // load (28 blocks x 2 tiles, one element per thread and block)
     for (int bi = 0; bi < NSB; ++bi)
         for (int bj = bi + 1; bj < NSB; ++bj) {
-            tile[(SB * bj + ec) * GP_TS + SB * bi + er] = 0.0;
-            invt[(SB * bj + ec) * GP_TS + SB * bi + er] = 0.0;
+            out_store<WT>(tile + (SB * bj + ec) * GP_TS + SB * bi + er, 0.0);
+            out_store<WT>(invt + (SB * bj + ec) * GP_TS + SB * bi + er, 0.0);
         }
     int bad = 0;
     DIAG_STAMP(0);
@@ -256,7 +264,7 @@ __device__ __forceinline__ void diag_potrf_inv_la_body(double* P, double* tile, 
                         for (int kk = 0; kk < 4; ++kk) wq[u] = mma_neg(accT[u][kk], bfrag(Wcur, kk, lane), wq[u]);
                         // W_pq[r = lane&15][c = (lane>>4)+4v] -> output tile of the inverse
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) invt[(SB * q + lg + 4 * v) * GP_TS + SB * p + li] = wq[u][v];
+                        for (int v = 0; v < 4; ++v) out_store<WT>(invt + (SB * q + lg + 4 * v) * GP_TS + SB * p + li, wq[u][v]);
                     }
                 }
             }
@@ -268,9 +276,9 @@ __device__ __forceinline__ void diag_potrf_inv_la_body(double* P, double* tile, 
             const int nel = (p + 2) * 256;
             for (int idx = t3; idx < nel; idx += 192) {
                 const int jb = idx >> 8, e = idx & 255, rr = e & 15, cc = e >> 4;
-                if (jb < p) tile[(SB * jb + cc) * GP_TS + SB * p + rr] = BLK(p, jb)[e];
-                else if (jb == p) tile[(SB * p + cc) * GP_TS + SB * p + rr] = (rr >= cc) ? Dpp[e] : 0.0;
-                else invt[(SB * p + cc) * GP_TS + SB * p + rr] = (rr >= cc) ? Wcur[e] : 0.0;
+                if (jb < p) out_store<WT>(tile + (SB * jb + cc) * GP_TS + SB * p + rr, BLK(p, jb)[e]);
+                else if (jb == p) out_store<WT>(tile + (SB * p + cc) * GP_TS + SB * p + rr, (rr >= cc) ? Dpp[e] : 0.0);
+                else out_store<WT>(invt + (SB * p + cc) * GP_TS + SB * p + rr, (rr >= cc) ? Wcur[e] : 0.0);
             }
         }
         DIAG_STAMP(4 + 4 * p);

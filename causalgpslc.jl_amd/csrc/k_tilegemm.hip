@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_nt_kernel(GemmArgs g) {
 // its column — the tile diag(tj) has already updated — instead of that tile being a work item of its own: all four waves load
 // its live rows, wave w computes the column blocks w and 7 - w.  Per output element the same MFMA chain as the stand-alone
 // item (ascending column block of X, then v): bit-identical.
-template <int WD, bool AUGEP = false>
+template <int WD, bool AUGEP = false, bool WT = false>
 __device__ __forceinline__ void strip_item(const GemmArgs& g, const int b, const int ti, const int tj, const bool no_update,
                                            const int nslab, double* lA, double* lB, const int tid, const int lane,
                                            const int wave, const int li, const int lg, const int frow_a, const int frow_b,
@@ -535,8 +535,13 @@ __device__ __forceinline__ void strip_item(const GemmArgs& g, const int b, const
                 }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                __builtin_nontemporal_store(st[0][v], Co + (16 * nc + 4 * v) * GP_TS);
-                __builtin_nontemporal_store(st[1][v], Co + (16 * nc + 4 * v) * GP_TS + 16);
+                if (WT) {       // task launch: write-through, so that the consumer workgroup needs no L2 write-back (out_store)
+                    out_store<true>(Co + (16 * nc + 4 * v) * GP_TS, st[0][v]);
+                    out_store<true>(Co + (16 * nc + 4 * v) * GP_TS + 16, st[1][v]);
+                } else {
+                    __builtin_nontemporal_store(st[0][v], Co + (16 * nc + 4 * v) * GP_TS);
+                    __builtin_nontemporal_store(st[1][v], Co + (16 * nc + 4 * v) * GP_TS + 16);
+                }
             }
         }
     }
@@ -571,8 +576,8 @@ __device__ __forceinline__ void strip_item(const GemmArgs& g, const int b, const
                 }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                Cg[(16 * nc + 4 * v) * GP_TS] = st[0][v];
-                if (mrows > 1) Cg[(16 * nc + 4 * v) * GP_TS + 16] = st[1][v];
+                out_store<WT>(Cg + (16 * nc + 4 * v) * GP_TS, st[0][v]);
+                if (mrows > 1) out_store<WT>(Cg + (16 * nc + 4 * v) * GP_TS + 16, st[1][v]);
             }
         };
         // every wave has read the whole tile before any wave overwrites a column block of it
@@ -672,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void tile_fused_strip_kernel(GemmArgs g) {
 // (The round-4 experiment that chained this INTO the strip kernel's launch — one launch per column, measured slower at every
 // size — lives in profiles/r04_chain_experiment.patch, not in the sources.)
 // ---------------------------------------------------------------------------------------
-template <int W, int MT>
+template <int W, int MT, bool WT = false>
 __device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, const int td, const int kd1, double* smem,
                                                 const int tid, const int lane) {
     // diagonal tile (td, td) -= sum_{kk in [g.k0, kd1)} A(td, kk) A(td, kk)^T -> packed LDS image (smem); augmented tile
@@ -790,8 +795,8 @@ __device__ __forceinline__ void syrk_chain_wave(const GemmArgs& g, const int b, 
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                Cg[(16 * W + 4 * v) * GP_TS + 16 * m] = ag[m][0][v];
-                Cg[(16 * (7 - W) + 4 * v) * GP_TS + 16 * m] = ag[m][1][v];
+                out_store<WT>(Cg + (16 * W + 4 * v) * GP_TS + 16 * m, ag[m][0][v]);
+                out_store<WT>(Cg + (16 * (7 - W) + 4 * v) * GP_TS + 16 * m, ag[m][1][v]);
             }
     }
 }
@@ -845,10 +850,13 @@ void launch_diag_update_potrf(const GemmArgs& g, int carry_aug, hipStream_t st) 
 // (PotrfTaskArgs::list), waits for the task's producers on the matrix's progress words, runs the body — exactly the
 // device functions of the per-column launches: strip_item, syrk_chain_wave + diag_potrf_inv_la_body, so every tile
 // receives the same MFMA chains in the same order and the factor is bit-identical — and publishes its own progress.
-// Hand-off between workgroups (MI355X_MICROARCH.md "inter-workgroup visibility", the plain-store form): every storing wave
-// drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane: agent-scope release fence, vmcnt(0) again (ROCm 7.2 can
-// drop the fence's own wait), relaxed agent-scope store of the progress word; consumer: ONE lane polls relaxed (bounded,
-// with s_sleep), ONE agent-scope acquire fence, vmcnt(0), workgroup barrier, then ordinary loads.
+// Hand-off between workgroups (MI355X_MICROARCH.md "inter-workgroup visibility", form R1): every tile another workgroup of the
+// launch will read is stored WRITE-THROUGH (agent-scope relaxed atomic stores = global_store ... sc1: out_store, diag_block.h),
+// every storing wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane stores the progress word (relaxed,
+// agent scope); consumer: ONE lane polls relaxed (bounded, with s_sleep), ONE agent-scope acquire fence, vmcnt(0), workgroup
+// barrier, then ordinary loads.  (The plain-store form — nt stores + an agent-scope release fence by one lane — is the
+// measurement build's GPSLC_TASK_FENCE=2 variant: 0.8 % slower at N = 1024, 3-4 % at N = 640 / 768, every fence writes the
+// XCD's whole L2 back; with NO release at all the consumers read stale tiles at once, profiles/r06_ab_experiments.md §1.)
 // No deadlock: inside a queue every task follows its producers (host order), tickets are handed out in that order, and
 // a workgroup that holds a ticket is running — the oldest unfinished ticket never waits for anything unfinished.
 // A poll that exceeds its bound (a bug, never a schedule) sets the time-out word: every workgroup then stops waiting, the
@@ -886,7 +894,7 @@ __device__ __forceinline__ unsigned task_fetch(const PotrfTaskArgs& a, int& q, i
     return TASK_NONE;
 }
 
-template <int MT>
+template <int MT, bool WT>
 __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // the fetching lane's state lives in LDS, and everything a body needs is recomputed from the thread index inside its
@@ -920,6 +928,7 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
                     if (k > 0) {
                         task_wait(prog + 1 + k, k, tmo);
                         if (MT > 0) task_wait(prog + 1 + nt, k, tmo);
+                        if (rows > 1) task_wait(prog + 2 + k, k, tmo);      // ... and tile row k + 1 for the strip it goes on with
                     }
                 } else {                            // strip(i.., k): inv(L_kk) and tile row k (diag(k)), the tile rows up to column k - 1
                     task_wait(prog, k + 1, tmo);
@@ -962,18 +971,27 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
             double* tile = tref_tile(a.g.C, b, k, k);
             double* invt = tref_tile(a.g.F, b, 0, k);
             if (k == 0) {
-                diag_potrf_inv_la_body(smem, tile, invt, a.g.info + b, a.g.info_base, tid, false);
+                diag_potrf_inv_la_body<WT>(smem, tile, invt, a.g.info + b, a.g.info_base, tid, false);
             } else {
                 switch (wave) {
-                    case 0: syrk_chain_wave<0, MT>(a.g, b, k, k, smem, tid, lane); break;
-                    case 1: syrk_chain_wave<1, MT>(a.g, b, k, k, smem, tid, lane); break;
-                    case 2: syrk_chain_wave<2, MT>(a.g, b, k, k, smem, tid, lane); break;
-                    default: syrk_chain_wave<3, MT>(a.g, b, k, k, smem, tid, lane); break;
+                    case 0: syrk_chain_wave<0, MT, WT>(a.g, b, k, k, smem, tid, lane); break;
+                    case 1: syrk_chain_wave<1, MT, WT>(a.g, b, k, k, smem, tid, lane); break;
+                    case 2: syrk_chain_wave<2, MT, WT>(a.g, b, k, k, smem, tid, lane); break;
+                    default: syrk_chain_wave<3, MT, WT>(a.g, b, k, k, smem, tid, lane); break;
                 }
-                diag_potrf_inv_la_body(smem, tile, invt, a.g.info + b, a.g.info_base + GP_TS * k, tid, true);
+                diag_potrf_inv_la_body<WT>(smem, tile, invt, a.g.info + b, a.g.info_base + GP_TS * k, tid, true);
             }
             __builtin_amdgcn_s_setprio(0);
-        } else {
+        }
+        // a diagonal task with the row bit set goes on with strip(k + 1, k) and the augmented tile of its column — the two tiles
+        // the NEXT diagonal task waits for — on the inverse it has just written (its own stores: drained, then a barrier); one
+        // fetch, acquire and release for both
+        const bool diag_then_strip = is_diag && rows > 1;
+        if (diag_then_strip) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if ((!is_diag && !is_back) || diag_then_strip) {
             const int li = lane & 15, lg = lane >> 4;
             int loff[4];
 #pragma unroll
@@ -986,9 +1004,14 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
             gl.fk = k;
             // `rows` consecutive tiles of the column, one after the other: they stream the same B panel, and the task's fetch,
             // acquire and release are paid once
-            for (int r = 0; r < rows; ++r)
-                strip_item<FUSE_WD, (MT > 0)>(gl, b, i + r, k, /*no_update=*/i >= a.nt, 8 * k, smem, smem + 2 * OPER_LDS, tid, lane,
-                                              wave, li, lg, lg * LROW + 32 * wave + li, lg * LROW + li, loff, 0, with_aug && r == 0);
+            if (diag_then_strip)
+                strip_item<FUSE_WD, (MT > 0), WT>(gl, b, k + 1, k, false, 8 * k, smem, smem + 2 * OPER_LDS, tid, lane, wave, li, lg,
+                                              lg * LROW + 32 * wave + li, lg * LROW + li, loff, 0, true);
+            else
+                for (int r = 0; r < rows; ++r)
+                    strip_item<FUSE_WD, (MT > 0), WT>(gl, b, i + r, k, /*no_update=*/i >= a.nt, 8 * k, smem, smem + 2 * OPER_LDS, tid,
+                                                  lane, wave, li, lg, lg * LROW + 32 * wave + li, lg * LROW + li, loff, 0,
+                                                  with_aug && r == 0);
         }
         // publish: every wave's stores have left the CU, then one lane releases and moves the matrix's progress word(s)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1001,10 +1024,15 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
             if (hit) dn = a.list[TASK_LIST_HDR + a.list[qn] + tnext];
             int* prog = a.sync + TASK_SYNC_HDR + (long long)b * TASK_SYNC_STRIDE;
             if (!is_back) {
-                if (GP_FENCE_MODE(a) == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (GP_FENCE_MODE(a) == 0 && !WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (is_diag) __hip_atomic_store(prog, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else
+                if (is_diag) {
+                    __hip_atomic_store(prog, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (diag_then_strip) {
+                        __hip_atomic_store(prog + 2 + k, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(prog + 1 + a.nt, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else
                     for (int r = 0; r < rows; ++r)
                         __hip_atomic_store(prog + 1 + i + r, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (with_aug) __hip_atomic_store(prog + 1 + a.nt, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1025,12 +1053,12 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
     }
 }
 
-template <int MT>
+template <int MT, bool WT>
 static void launch_potrf_tasks_t(const PotrfTaskArgs& a, unsigned grid, hipStream_t st) {
     static DeviceOnce once;
     constexpr int bytes = DIAG3_LDS_BYTES > GEMM_LDS_BYTES ? DIAG3_LDS_BYTES : GEMM_LDS_BYTES;
-    lds_opt_in(once, (const void*)potrf_tasks_kernel<MT>, bytes);
-    hipLaunchKernelGGL(potrf_tasks_kernel<MT>, dim3(grid), dim3(256), bytes, st, a);
+    lds_opt_in(once, (const void*)potrf_tasks_kernel<MT, WT>, bytes);
+    hipLaunchKernelGGL((potrf_tasks_kernel<MT, WT>), dim3(grid), dim3(256), bytes, st, a);
 }
 
 // mt: 16-row blocks (1 or 2) of the augmented right-hand-side row that ride with the diagonal tasks
@@ -1041,8 +1069,15 @@ void launch_potrf_tasks(const PotrfTaskArgs& a, long long ntasks, int mt, hipStr
     slots = diag_env("GPSLC_GEMM_SLOTS", slots);
 #endif
     const unsigned grid = (unsigned)(ntasks < slots ? ntasks : slots);
-    if (mt <= 1) launch_potrf_tasks_t<1>(a, grid, st);
-    else launch_potrf_tasks_t<2>(a, grid, st);
+#ifdef GPSLC_DIAG
+    if (a.fence_mode & 2) {      // measurement build, GPSLC_TASK_FENCE bit 1: plain / nt payload stores + an agent-scope release fence
+        if (mt <= 1) launch_potrf_tasks_t<1, false>(a, grid, st);
+        else launch_potrf_tasks_t<2, false>(a, grid, st);
+        return;
+    }
+#endif
+    if (mt <= 1) launch_potrf_tasks_t<1, true>(a, grid, st);
+    else launch_potrf_tasks_t<2, true>(a, grid, st);
 }
 
 // ---------------------------------------------------------------------------------------

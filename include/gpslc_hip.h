@@ -75,7 +75,7 @@ int gpslc_set_tuning(gpslc_ctx* ctx, int32_t max_batch, int32_t panel_tiles, int
  * side (and at most panel_tiles wide: one left-looking panel) are factorised — and, where MeanITE is wanted, back-substituted
  * (src/estimation.jl:46's CovWWp \ Y) — by ONE persistent launch of tile tasks: diagonal-tile, strip and back-substitution
  * tasks of many matrices in flight at once, dependencies through per-matrix progress words, instead of one launch per
- * tile column.  Every output is bit-identical either way.  min_tiles: <= 0 = keep (default 5: N > 512; below, one launch
+ * tile column.  Every output is bit-identical either way.  min_tiles: <= 0 = keep (default 4: N > 384; below, one launch
  * per column is faster); max_tiles: 0 = always one launch per column, negative = keep (default 8: N <= 1024), at most 24;
  * group: matrices per group of the task order, <= 0 = keep (default 8).  Returns 0, or minus the number of the offending
  * argument. */
