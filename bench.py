@@ -615,7 +615,7 @@ def main():
     ctx = gp.Context(n, D, K, device=local_rank, profile=not a.no_profile, fp32_kernel=a.fp32_kernel)
     ctx.check(ctx.lib.gpslc_set_data_dev(ctx.h, ptr(dX), ptr(dT), ptr(dY)))
     ctx.set_tuning(a.max_batch, a.panel, a.streams)
-    ctx.set_task_schedule(a.task_min_tiles, a.task_tiles, a.task_group)
+    ctx.set_task_schedule(a.task_min_tiles, a.task_tiles, 0, a.task_group)
 
     gathered_m = [torch.empty_like(mS) for _ in range(world)] if use_dist else None
     gathered_v = [torch.empty_like(vS) for _ in range(world)] if use_dist else None

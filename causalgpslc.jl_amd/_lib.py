@@ -52,7 +52,7 @@ SIGNATURES = {
     "gpslc_set_data": (C.c_int, [C.c_void_p, _D, _D, _D]),
     "gpslc_set_data_dev": (C.c_int, [C.c_void_p, _D, _D, _D]),
     "gpslc_set_tuning": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
-    "gpslc_set_task_schedule": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "gpslc_set_task_schedule": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gpslc_set_ensemble": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
     "gpslc_last_error": (C.c_char_p, [C.c_void_p]),
     "gpslc_rbf_log": (C.c_int, [C.c_void_p, _D, _D, C.c_int64, C.c_int32, _D, C.c_int32, _D]),

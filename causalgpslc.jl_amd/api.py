@@ -83,10 +83,10 @@ class Context:
     def set_tuning(self, max_batch=0, panel_tiles=0, n_streams=0):
         self.check(self.lib.gpslc_set_tuning(self.h, max_batch, panel_tiles, n_streams))
 
-    def set_task_schedule(self, min_tiles=0, max_tiles=-1, group=0):
-        """Persistent factorisation launch for matrices of min_tiles .. max_tiles tiles per side (max_tiles = 0: off;
-        0 / -1 / 0 = keep)."""
-        self.check(self.lib.gpslc_set_task_schedule(self.h, min_tiles, max_tiles, group))
+    def set_task_schedule(self, min_tiles=0, max_tiles=-1, min_matrices=0, group=0):
+        """Persistent factorisation launch for chunks of at least min_matrices matrices of min_tiles .. max_tiles tiles per
+        side (max_tiles = 0: off; 0 / -1 / 0 / 0 = keep)."""
+        self.check(self.lib.gpslc_set_task_schedule(self.h, min_tiles, max_tiles, min_matrices, group))
 
     def set_ensemble(self, sample_offset=0, S_total=0):
         """Placement of the next calls' samples inside a larger ensemble (Philox stream ids): gpslc_set_ensemble."""

@@ -138,6 +138,9 @@ struct gpslc_ctx {
     bool task_used = false;
     int task_min_nt = 4, task_max_nt = 8;   // tile counts in this range take the persistent launch (384 < N <= 1024; below, one
                                             // launch per column is faster — N = 384: -6 %, profiles/r06_ab_experiments.md §1)
+    int task_min_batch = 256;      // ... when the chunk holds at least this many matrices: a persistent launch over few
+                                   // matrices is a chain of hand-offs (N = 1024: 2.1 ms for 8 matrices against 1.5 ms with one
+                                   // launch per column; even at 256, profiles/r06_ab_experiments.md §1)
     int task_group = 8;            // matrices per group of the task order (see build_task_list)
     int task_rows = 2;             // consecutive tile rows of a column per strip task
     Arena scratch;                 // call-level buffers (internal MeanITE of a draws-only call, ...)
@@ -476,7 +479,7 @@ bool potrf_tasks_ok(const gpslc_ctx* c, int nt, int ntot, int short_rows, bool s
     static const int on = diag_env("GPSLC_TASKS", 1);
     // one left-looking panel only: the panel knob of gpslc_set_tuning keeps its meaning
     if (!on || !inv || nt < std::max(2, c->task_min_nt) || nt > std::min(std::min(c->task_max_nt, TASK_MAX_NT), std::max(1, c->panel)) ||
-        nb >= TASK_MAX_BATCH)
+        nb >= TASK_MAX_BATCH || nb < c->task_min_batch)
         return false;
     return ntot == nt + 1 && short_rows > 0 && short_rows <= 32 && skip_aug_diag;
 }
@@ -1453,13 +1456,14 @@ int gpslc_set_tuning(gpslc_ctx* c, int32_t max_batch, int32_t panel_tiles, int32
     return GPSLC_OK;
 }
 
-int gpslc_set_task_schedule(gpslc_ctx* c, int32_t min_tiles, int32_t max_tiles, int32_t group) {
+int gpslc_set_task_schedule(gpslc_ctx* c, int32_t min_tiles, int32_t max_tiles, int32_t min_matrices, int32_t group) {
     if (!c) return -1;
     if (min_tiles > TASK_MAX_NT) return -2;
     if (max_tiles > TASK_MAX_NT) return -3;
-    if (group > 4096) return -4;
+    if (group > 4096) return -5;
     if (min_tiles > 0) c->task_min_nt = min_tiles;
     if (max_tiles >= 0) c->task_max_nt = max_tiles;
+    if (min_matrices > 0) c->task_min_batch = min_matrices;
     if (group > 0) c->task_group = group;
     return GPSLC_OK;
 }

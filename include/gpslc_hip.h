@@ -71,15 +71,16 @@ int gpslc_set_data_dev(gpslc_ctx* ctx, const double* X, const double* T, const d
 int gpslc_set_tuning(gpslc_ctx* ctx, int32_t max_batch, int32_t panel_tiles, int32_t n_streams);
 
 /* Schedule of the factorisation of A at small tile counts (round 6; no reference counterpart: the reference factorises
- * one matrix at a time, src/likelihood.jl:42-43, src/estimation.jl:46).  Matrices of min_tiles .. max_tiles tiles of 128 per
- * side (and at most panel_tiles wide: one left-looking panel) are factorised — and, where MeanITE is wanted, back-substituted
- * (src/estimation.jl:46's CovWWp \ Y) — by ONE persistent launch of tile tasks: diagonal-tile, strip and back-substitution
- * tasks of many matrices in flight at once, dependencies through per-matrix progress words, instead of one launch per
- * tile column.  Every output is bit-identical either way.  min_tiles: <= 0 = keep (default 4: N > 384; below, one launch
- * per column is faster); max_tiles: 0 = always one launch per column, negative = keep (default 8: N <= 1024), at most 24;
- * group: matrices per group of the task order, <= 0 = keep (default 8).  Returns 0, or minus the number of the offending
- * argument. */
-int gpslc_set_task_schedule(gpslc_ctx* ctx, int32_t min_tiles, int32_t max_tiles, int32_t group);
+ * one matrix at a time, src/likelihood.jl:42-43, src/estimation.jl:46).  Chunks of at least min_matrices matrices of
+ * min_tiles .. max_tiles tiles of 128 per side (and at most panel_tiles wide: one left-looking panel) are factorised — and,
+ * where MeanITE is wanted, back-substituted (src/estimation.jl:46's CovWWp \ Y) — by ONE persistent launch of tile tasks:
+ * diagonal-tile, strip and back-substitution tasks of many matrices in flight at once, dependencies through per-matrix
+ * progress words, instead of one launch per tile column.  Every output is bit-identical either way.
+ * min_tiles: <= 0 = keep (default 4: N > 384; below, one launch per column is faster); max_tiles: 0 = always one launch per
+ * column, negative = keep (default 8: N <= 1024), at most 24; min_matrices: <= 0 = keep (default 256: a persistent launch
+ * over a few matrices is a chain of hand-offs — the single scores of an MH step keep the per-column launches); group:
+ * matrices per group of the task order, <= 0 = keep (default 8).  Returns 0, or minus the number of the offending argument. */
+int gpslc_set_task_schedule(gpslc_ctx* ctx, int32_t min_tiles, int32_t max_tiles, int32_t min_matrices, int32_t group);
 
 /* Placement of a call's posterior samples inside a larger ensemble, for the library's own normals (z_or_null == NULL):
  * after gpslc_set_ensemble(ctx, s_off, S_total) sample s, level l of gpslc_predict[_dev] draws from the Philox stream

@@ -112,9 +112,10 @@ set_data_dev!(c::Ctx, X::Ptr{Float64}, T::Ptr{Float64}, Y::Ptr{Float64}) = check
 
 set_tuning!(c::Ctx; max_batch::Integer=0, panel_tiles::Integer=0, n_streams::Integer=0) = check(c,
     ccall((:gpslc_set_tuning, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Int32), c.h, max_batch, panel_tiles, n_streams))
-# persistent factorisation launch for min_tiles .. max_tiles tiles per side (max_tiles = 0: one launch per tile column; 0 / -1 / 0: keep)
-set_task_schedule!(c::Ctx; min_tiles::Integer=0, max_tiles::Integer=-1, group::Integer=0) = check(c,
-    ccall((:gpslc_set_task_schedule, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Int32), c.h, min_tiles, max_tiles, group))
+# persistent factorisation launch for chunks of >= min_matrices matrices of min_tiles .. max_tiles tiles per side
+# (max_tiles = 0: one launch per tile column; 0 / -1 / 0 / 0: keep)
+set_task_schedule!(c::Ctx; min_tiles::Integer=0, max_tiles::Integer=-1, min_matrices::Integer=0, group::Integer=0) = check(c,
+    ccall((:gpslc_set_task_schedule, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32), c.h, min_tiles, max_tiles, min_matrices, group))
 
 """Placement of the next calls' posterior samples inside a larger ensemble (a rank's block [s0, s1) of S_total): the
 library's own normals then do not depend on how the ensemble is sharded.  S_total = 0 restores the default."""

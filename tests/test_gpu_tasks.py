@@ -19,9 +19,9 @@ def _same(a, b):
 
 def _both(gp, c, doT, max_batch=0, group=0, **kw):
     out = []
-    for tiles in (8, 0):                       # persistent launch (from 2 tiles per side on), one launch per column
+    for tiles in (8, 0):                       # persistent launch (from 2 tiles per side and ONE matrix on), one launch per column
         g = cases.gpslc_object(gp, c)
-        g.ctx().set_task_schedule(2, tiles, group)
+        g.ctx().set_task_schedule(2, tiles, 1, group)
         if max_batch:
             g.ctx().set_tuning(max_batch, 0, 0)
         out.append(gp.predict(g, doT, want_mean_ite=True, **kw))
@@ -60,7 +60,7 @@ def test_task_launch_draws_and_logpdf_paths(gp):
     outs = []
     for tiles in (8, 0):
         g = cases.gpslc_object(gp, c)
-        g.ctx().set_task_schedule(2, tiles, 0)
+        g.ctx().set_task_schedule(2, tiles, 1, 0)
         ms, vs, mi, dr = gp.predict(g, [0.1, 0.6], want_mean_ite=True, spp=3, seed=5, want_draws=True)
         outs.append((ms, vs, mi, dr, gp.yLogpdf(g)))
     for x, y in zip(*outs):
@@ -77,7 +77,7 @@ def test_failing_pivot_is_reported_by_the_task_launch(gp, bad):
     infos, per_sample = [], []
     for tiles in (8, 0):
         g = cases.gpslc_object(gp, c)
-        g.ctx().set_task_schedule(2, tiles, 0)
+        g.ctx().set_task_schedule(2, tiles, 1, 0)
         with pytest.raises(gp.PosDefException) as ei:
             gp.predict(g, [0.3])
         infos.append(ei.value.info)
@@ -91,8 +91,8 @@ def test_set_task_schedule_arguments(gp):
     c = cases.make_case(24, "UX", False, S=2, seed=2)
     g = cases.gpslc_object(gp, c)
     lib, h = g.ctx().lib, g.ctx().h
-    assert lib.gpslc_set_task_schedule(h, 25, 8, 0) == -2
-    assert lib.gpslc_set_task_schedule(h, 2, 25, 0) == -3
-    assert lib.gpslc_set_task_schedule(h, 2, 8, 5000) == -4
-    assert lib.gpslc_set_task_schedule(h, 0, -1, 0) == 0
-    assert lib.gpslc_set_task_schedule(None, 2, 8, 8) == -1
+    assert lib.gpslc_set_task_schedule(h, 25, 8, 0, 0) == -2
+    assert lib.gpslc_set_task_schedule(h, 2, 25, 0, 0) == -3
+    assert lib.gpslc_set_task_schedule(h, 2, 8, 1, 5000) == -5
+    assert lib.gpslc_set_task_schedule(h, 0, -1, 0, 0) == 0
+    assert lib.gpslc_set_task_schedule(None, 2, 8, 1, 8) == -1
