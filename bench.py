@@ -46,13 +46,14 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBPS = 8000.0
 # Three figures (HBM bytes per posterior sample at config 2; Gram / MeanITE fp64-VALU issue time per sample) are MEASURED
-# quantities: they live in profiles/r05_bench_constants.json, each stamped with the git blob hashes of the sources it was measured
+# quantities: they live in profiles/r06_bench_constants.json, each stamped with the git blob hashes of the sources it was measured
 # on (tools/collect_profiles.py), and are withheld — like roofline.traffic — when any of those sources has changed since.
 CSRC = os.path.join(ROOT, "causalgpslc.jl_amd", "csrc")
 KERNEL_SRC = os.path.join(CSRC, "k_tilegemm.hip")
-PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_pmc_tile_gemm.json") for r in ("r05", "r04"))
-                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r05_pmc_tile_gemm.json"))
-BENCH_CONSTANTS = os.path.join(ROOT, "profiles", "r05_bench_constants.json")
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_pmc_tile_gemm.json") for r in ("r06", "r05", "r04"))
+                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r06_pmc_tile_gemm.json"))
+BENCH_CONSTANTS = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_bench_constants.json") for r in ("r06", "r05"))
+                        if os.path.exists(p)), os.path.join(ROOT, "profiles", "r06_bench_constants.json"))
 
 
 def parse():
@@ -122,7 +123,7 @@ def pmc_traffic(default_config):
 
 
 def measured_constant(name):
-    """(value, note) of a measured constant of profiles/r05_bench_constants.json, or (None, reason) when the file is missing or
+    """(value, note) of a measured constant of profiles/r06_bench_constants.json, or (None, reason) when the file is missing or
     one of the sources the measurement was taken on has changed (git blob hash) — a remembered number must not describe a
     kernel it was not measured on."""
     if not os.path.exists(BENCH_CONSTANTS):
@@ -892,7 +893,7 @@ def main():
                                          "BASELINE configs[1] AS STATED: Synthetic N=1024 D=4 nU=1 continuous treatment, "
                                          "1k posterior samples = ONE gpslc_predict_dev call per step (S = 1000: one chunk, "
                                          "a chain of dependent launches with nothing else in flight), fp64, unit A with "
-                                         "MeanITE, L=1; kernel launches per call: profiles/r04_c2_literal_kernel_stats.md"),
+                                         "MeanITE, L=1; kernel launches per call: profiles/r06_c2_literal_kernel_stats.md"),
                 "c3_literal": run_config(gp, synth, np, torch, dev, local_rank, 4096, 8, 2, 5000, 1, False, False, 1, 1,
                                          "BASELINE configs[2] AS STATED: Synthetic N=4096 D=8 nU=2, 5k posterior samples = ONE "
                                          "gpslc_predict_dev call per step (S = 5000: five internal chunks of <= 1,024 matrices), "
