@@ -74,6 +74,8 @@ def parse():
                          "factorisation launch (0 = one launch per tile column, -1 = the library's default)")
     ap.add_argument("--task-min-tiles", type=int, default=0, help="gpslc_set_task_schedule: smallest tile count that takes the "
                                                                   "persistent launch (0 = the library's default)")
+    ap.add_argument("--task-min-matrices", type=int, default=0, help="gpslc_set_task_schedule: smallest chunk (matrices) that takes "
+                                                                     "the persistent launch (0 = the library's default)")
     ap.add_argument("--task-group", type=int, default=0, help="gpslc_set_task_schedule: matrices per group of the task order")
     ap.add_argument("--no-mean-ite", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -616,7 +618,7 @@ def main():
     ctx = gp.Context(n, D, K, device=local_rank, profile=not a.no_profile, fp32_kernel=a.fp32_kernel)
     ctx.check(ctx.lib.gpslc_set_data_dev(ctx.h, ptr(dX), ptr(dT), ptr(dY)))
     ctx.set_tuning(a.max_batch, a.panel, a.streams)
-    ctx.set_task_schedule(a.task_min_tiles, a.task_tiles, 0, a.task_group)
+    ctx.set_task_schedule(a.task_min_tiles, a.task_tiles, a.task_min_matrices, a.task_group)
 
     gathered_m = [torch.empty_like(mS) for _ in range(world)] if use_dist else None
     gathered_v = [torch.empty_like(vS) for _ in range(world)] if use_dist else None

@@ -124,6 +124,7 @@ struct gpslc_ctx {
     bool binary_t = false;   // every treatment is exactly 0 or 1 (detected in gpslc_set_data)
     int max_batch = 0;   // 0 = auto
     int panel = 8;
+    bool panel_set = false;        // gpslc_set_tuning gave a panel width: the persistent launch then serves nt <= panel only
     int64_t ens_off = 0, ens_S = 0;   // gpslc_set_ensemble: placement of a call's samples for the Philox stream ids
     int nstreams = 1;   // chunks of one call alternate over this many HIP streams (2 buys ~1-2 %, see profiles/)
     std::vector<hipStream_t> streams;
@@ -136,12 +137,13 @@ struct gpslc_ctx {
     std::vector<TaskList> task_lists;
     unsigned long long task_clock = 0;
     bool task_used = false;
-    int task_min_nt = 4, task_max_nt = 8;   // tile counts in this range take the persistent launch (384 < N <= 1024; below, one
-                                            // launch per column is faster — N = 384: -6 %, profiles/r06_ab_experiments.md §1)
+    int task_min_nt = 2, task_max_nt = 24;   // tile counts in this range take the persistent launch (128 < N <= 3072: with
+                                            // groups of 32 it wins at every tile count the descriptor can hold — N = 256 +3 %, 384 +6 %, 1280 / 1536
+                                            // +4 %, 2048 .. 3072 +1..1.7 % against panel 8 + trailing updates, profiles/r06_ab_experiments.md §1d)
     int task_min_batch = 256;      // ... when the chunk holds at least this many matrices: a persistent launch over few
                                    // matrices is a chain of hand-offs (N = 1024: 2.1 ms for 8 matrices against 1.5 ms with one
                                    // launch per column; even at 256, profiles/r06_ab_experiments.md §1)
-    int task_group = 8;            // matrices per group of the task order (see build_task_list)
+    int task_group = 32;           // matrices per group of the task order (see build_task_list)
     int task_rows = 2;             // consecutive tile rows of a column per strip task
     Arena scratch;                 // call-level buffers (internal MeanITE of a draws-only call, ...)
     PoolArena io;                  // staging of the host-pointer entry points and per-call info words
@@ -477,8 +479,10 @@ const TaskList& task_list_for(gpslc_ctx* c, int nt, int back, int nb, int G, int
 // (EpiArgs::from_rows) — the shape of run_predict's factorisation of A at N <= 128 task_max_nt
 bool potrf_tasks_ok(const gpslc_ctx* c, int nt, int ntot, int short_rows, bool skip_aug_diag, int nb, const double* inv) {
     static const int on = diag_env("GPSLC_TASKS", 1);
-    // one left-looking panel only: the panel knob of gpslc_set_tuning keeps its meaning
-    if (!on || !inv || nt < std::max(2, c->task_min_nt) || nt > std::min(std::min(c->task_max_nt, TASK_MAX_NT), std::max(1, c->panel)) ||
+    // one left-looking panel only: a panel width given through gpslc_set_tuning keeps its meaning (nt beyond it takes the panel
+    // schedule); with the default width the persistent launch factorises the whole matrix as ONE panel up to task_max_nt
+    const int pmax = c->panel_set ? std::max(1, c->panel) : TASK_MAX_NT;
+    if (!on || !inv || nt < std::max(2, c->task_min_nt) || nt > std::min(std::min(c->task_max_nt, TASK_MAX_NT), pmax) ||
         nb >= TASK_MAX_BATCH || nb < c->task_min_batch)
         return false;
     return ntot == nt + 1 && short_rows > 0 && short_rows <= 32 && skip_aug_diag;
@@ -1451,7 +1455,7 @@ int gpslc_set_tuning(gpslc_ctx* c, int32_t max_batch, int32_t panel_tiles, int32
     if (panel_tiles < 0) return -3;
     if (n_streams < 0 || n_streams > 8) return -4;
     if (max_batch > 0) c->max_batch = max_batch;
-    if (panel_tiles > 0) c->panel = panel_tiles;
+    if (panel_tiles > 0) { c->panel = panel_tiles; c->panel_set = true; }
     if (n_streams > 0) c->nstreams = n_streams;
     return GPSLC_OK;
 }

@@ -76,10 +76,11 @@ int gpslc_set_tuning(gpslc_ctx* ctx, int32_t max_batch, int32_t panel_tiles, int
  * where MeanITE is wanted, back-substituted (src/estimation.jl:46's CovWWp \ Y) — by ONE persistent launch of tile tasks:
  * diagonal-tile, strip and back-substitution tasks of many matrices in flight at once, dependencies through per-matrix
  * progress words, instead of one launch per tile column.  Every output is bit-identical either way.
- * min_tiles: <= 0 = keep (default 4: N > 384; below, one launch per column is faster); max_tiles: 0 = always one launch per
- * column, negative = keep (default 8: N <= 1024), at most 24; min_matrices: <= 0 = keep (default 256: a persistent launch
+ * min_tiles: <= 0 = keep (default 2: N > 128); max_tiles: 0 = always one launch per column, negative = keep (default and
+ * limit 24: N <= 3072 — beyond one panel of gpslc_set_tuning's panel_tiles, when that was given, the panel schedule is kept:
+ * left-looking panels of per-column launches + one trailing update per panel); min_matrices: <= 0 = keep (default 256: a persistent launch
  * over a few matrices is a chain of hand-offs — the single scores of an MH step keep the per-column launches); group:
- * matrices per group of the task order, <= 0 = keep (default 8).  Returns 0, or minus the number of the offending argument. */
+ * matrices per group of the task order, <= 0 = keep (default 32).  Returns 0, or minus the number of the offending argument. */
 int gpslc_set_task_schedule(gpslc_ctx* ctx, int32_t min_tiles, int32_t max_tiles, int32_t min_matrices, int32_t group);
 
 /* Placement of a call's posterior samples inside a larger ensemble, for the library's own normals (z_or_null == NULL):

@@ -40,6 +40,31 @@ def test_task_launch_equals_the_per_column_schedule_bit_for_bit(gp, n, S, L):
         _same(x, y)
 
 
+@pytest.mark.parametrize("n,S,L", [(1100, 5, 2), (1536, 3, 1), (2048, 9, 1), (2500, 2, 20), (3072, 3, 1)])
+def test_task_launch_as_one_panel_beyond_eight_tiles(gp, n, S, L):
+    """nt = 9, 12, 16, 20, 24 (the descriptor's limit): with the default panel width the persistent launch factorises the whole
+    matrix as ONE left-looking panel; the per-column schedule it is compared with runs panels of 8 + trailing updates — different
+    launches, the same MFMA chain per tile (ascending k): bit-identical.  A panel width given through gpslc_set_tuning keeps the
+    panel schedule beyond it."""
+    c = cases.make_case(n, "UX", False, S=S, seed=n + S)
+    doT = np.linspace(-0.5, 0.7, L)
+    out = []
+    for tiles, panel in ((24, 0), (0, 0), (24, 8)):
+        g = cases.gpslc_object(gp, c)
+        g._ctx = gp.Context(g.getN(), g.getNX(), g.getNU(), profile=True)      # HIP-event records: which schedule really ran
+        g._ctx.set_data(g.X, g.T, g.Y)
+        g.ctx().set_task_schedule(2, tiles, 1, 0)
+        if panel:
+            g.ctx().set_tuning(0, panel, 0)
+        g.ctx().profile_reset()
+        out.append(gp.predict(g, doT, want_mean_ite=True))
+        launches = g.ctx().profile_get(4)[0]
+        assert (launches > 0) == (tiles > 0 and not panel)
+    for other in out[1:]:
+        for x, y in zip(out[0], other):
+            _same(x, y)
+
+
 @pytest.mark.parametrize("group", [1, 3, 64])
 def test_task_order_group_size_and_chunking_do_not_change_results(gp, group):
     """Group size 1 puts a task right behind its producer in the queue (consumers really wait on the progress words);
