@@ -50,8 +50,12 @@ HBM_PEAK_GBPS = 8000.0
 # on (tools/collect_profiles.py), and are withheld — like roofline.traffic — when any of those sources has changed since.
 CSRC = os.path.join(ROOT, "causalgpslc.jl_amd", "csrc")
 KERNEL_SRC = os.path.join(CSRC, "k_tilegemm.hip")
-PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_pmc_tile_gemm.json") for r in ("r06", "r05", "r04"))
-                    if os.path.exists(p)), os.path.join(ROOT, "profiles", "r06_pmc_tile_gemm.json"))
+def pmc_summary_path(stem):
+    """the newest committed PMC summary profiles/rNN_<stem>.json"""
+    return next((p for p in (os.path.join(ROOT, "profiles", f"{r}_{stem}.json") for r in ("r06", "r05", "r04"))
+                 if os.path.exists(p)), os.path.join(ROOT, "profiles", f"r06_{stem}.json"))
+
+
 BENCH_CONSTANTS = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_bench_constants.json") for r in ("r06", "r05"))
                         if os.path.exists(p)), os.path.join(ROOT, "profiles", "r06_bench_constants.json"))
 
@@ -92,6 +96,8 @@ def parse():
     ap.add_argument("--config4-levels", type=int, default=64)
     ap.add_argument("--config4-steps", type=int, default=2)
     ap.add_argument("--no-configs", action="store_true", help="skip the short timed runs of BASELINE configs[1] and configs[4]")
+    ap.add_argument("--no-panel-leg", action="store_true", help="skip the short leg that times the panel schedule of rounds 1-5 "
+                                                                  "beside the default one (roofline.panel_schedule)")
     ap.add_argument("--no-multi-abi", action="store_true", help="skip the timing of gpslc_predict_multi's host delivery")
     ap.add_argument("--binary-t", action="store_true", help="Bernoulli(0.5) treatments (BASELINE config 5 shape)")
     ap.add_argument("--fp32-kernel", action="store_true", help="mixed precision: RBF evaluation in fp32 (config 5)")
@@ -111,17 +117,18 @@ def git_blob_sha(path):
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
-def pmc_traffic(default_config):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of the default command, or None with the
-    reason: the summary records the git blob hash of the kernel source it was taken from, and a different source today
-    means the number no longer describes this kernel."""
-    if not default_config or not os.path.exists(PMC_SUMMARY):
+def pmc_traffic(default_config, stem="pmc_tile_gemm"):
+    """HBM bytes per launch of the dominant kernel (stem: which kernel's summary) from the committed PMC passes of the default
+    command, or None with the reason: the summary records the git blob hash of the kernel source it was taken from, and a
+    different source today means the number no longer describes this kernel."""
+    path = pmc_summary_path(stem)
+    if not default_config or not os.path.exists(path):
         return None, "no PMC summary for this configuration"
-    pm = json.load(open(PMC_SUMMARY))
+    pm = json.load(open(path))
     if pm.get("kernel_src_sha") != git_blob_sha(KERNEL_SRC):
-        return None, f"STALE: k_tilegemm.hip changed since {os.path.relpath(PMC_SUMMARY, ROOT)} was taken; withheld"
+        return None, f"STALE: k_tilegemm.hip changed since {os.path.relpath(path, ROOT)} was taken; withheld"
     return pm.get("hbm_bytes_per_launch"), ("bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), "
-                                             f"{os.path.relpath(PMC_SUMMARY, ROOT)}; kernel source hash matches")
+                                             f"{os.path.relpath(path, ROOT)}; kernel source hash matches")
 
 
 def measured_constant(name):
@@ -658,7 +665,7 @@ def main():
         dt = float(tt.item())
     launches, kms, kflop = ctx.profile_get(0)      # tile_gemm_nt_kernel<1, 0>: the dominant kernel
     launches1, kms1, kflop1 = ctx.profile_get(1)   # tile_fused_strip_kernel: in-panel column update fused with the panel solve
-    ctx_prof4 = ctx.profile_get(4)                 # potrf_tasks_kernel: the persistent factorisation launch (N <= 1024)
+    ctx_prof4 = ctx.profile_get(4)                 # potrf_tasks_kernel: the persistent factorisation launch (N <= 4096)
     # the spread of the measurement: the same K steps timed again (--repeats - 1 more regions, bracketed like the first).  `value`
     # stays the FIRST region (exactly K steps after W warm-up steps, as the contract says); value_runs lists all of them.
     region_s = [dt]
@@ -676,6 +683,40 @@ def main():
         region_s.append(d1)
     kname = "tile_gemm_nt_kernel<1, 0> (f64 MFMA tile update: trailing updates of the blocked Cholesky)"
     kname1 = "tile_fused_strip_kernel<8> (f64 MFMA tile update: in-panel column update fused with the panel solve)"
+    # Round 6: at the default sizes the whole factorisation is ONE persistent launch of tile tasks.  The schedule of rounds 1-5
+    # (left-looking panels of 8 tile columns, one launch per column, one trailing update per panel) is timed beside it in a short
+    # untimed-for-`value` leg, so that the trailing-update kernel's roofline figure stays comparable across rounds.
+    panel_leg = None
+    if ctx_prof4[1] > 0 and a.task_tiles < 0 and not a.timing_only and not a.no_profile and not a.no_panel_leg:
+        ctx.set_task_schedule(0, 0, 0, 0)
+        step()
+        ctx.profile_reset()
+        fence()
+        tp = time.perf_counter()
+        psteps = min(a.steps, 3)
+        for _ in range(psteps):
+            step()
+        fence()
+        dtp = time.perf_counter() - tp
+        if use_dist:
+            tt = torch.tensor([dtp], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtp = float(tt.item())
+        pl0, pms0, pfl0 = ctx.profile_get(0)
+        pl1, pms1, pfl1 = ctx.profile_get(1)
+        panel_leg = {"what": "the same step with one launch per tile column (gpslc_set_task_schedule(max_tiles = 0): panels of 8 tile "
+                             "columns + one trailing update per panel, the schedule of rounds 1-5), timed after the regions above",
+                     "value": Sr * world * psteps / dtp, "unit": "posterior samples/s", "steps": psteps,
+                     "ms_per_step": 1e3 * dtp / psteps}
+        if pl0 > 0 and pms0 > 0:
+            panel_leg["trailing_update_kernel"] = {"kernel": kname, "achieved": pfl0 / (pms0 * 1e-3) / 1e12,
+                                                   "frac": pfl0 / (pms0 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "launches": int(pl0),
+                                                   "avg_launch_ms": pms0 / pl0, "share_of_step_time": pms0 * 1e-3 / dtp}
+        if pl1 > 0 and pms1 > 0:
+            panel_leg["fused_in_panel_kernel"] = {"kernel": kname1, "achieved": pfl1 / (pms1 * 1e-3) / 1e12,
+                                                  "frac": pfl1 / (pms1 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "launches": int(pl1),
+                                                  "avg_launch_ms": pms1 / pl1, "share_of_step_time": pms1 * 1e-3 / dtp}
+        ctx.set_task_schedule(a.task_min_tiles, 32, a.task_min_matrices, a.task_group)
 
     # ---- BASELINE configs[3]: the same posterior samples x 64 intervention levels (the sweep of
     # src/prediction.jl:30-33 over src/estimation.jl:78-84), sharded like the L = 1 region: second timed region
@@ -775,7 +816,7 @@ def main():
         kname, kname1 = kname1, kname
     launches4, kms4, kflop4 = ctx_prof4
     if kms4 > kms:
-        # N <= 1024 with the default schedule: the whole factorisation is ONE persistent launch of tile tasks
+        # N <= 4096 with the default schedule: the whole factorisation is ONE persistent launch of tile tasks
         launches1, kms1, kflop1 = launches, kms, kflop
         kname1 = kname
         launches, kms, kflop = launches4, kms4, kflop4
@@ -813,7 +854,8 @@ def main():
             # rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950 correction; tools/profile_r04.sh).  The
             # summary records the git blob hash of the kernel source it was taken from: a different source today
             # means the number no longer describes this kernel, and it is withheld.
-            traffic, tnote = pmc_traffic((n, D, K, L, Sr) == (4096, 8, 2, 1, 1024) and a.max_batch == 0 and a.panel == 0)
+            traffic, tnote = pmc_traffic((n, D, K, L, Sr) == (4096, 8, 2, 1, 1024) and a.max_batch == 0 and a.panel == 0,
+                                         "pmc_potrf_tasks" if kname.startswith("potrf_tasks") else "pmc_tile_gemm")
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_note": tnote,
                                "kernel": kname,
@@ -826,6 +868,8 @@ def main():
                     "achieved": kflop1 / (kms1 * 1e-3) / 1e12, "frac": kflop1 / (kms1 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                     "launches": int(launches1), "avg_launch_ms": kms1 / launches1,
                     "share_of_step_time": kms1 * 1e-3 / dt}
+        if panel_leg is not None and "roofline" in out:
+            out["roofline"]["panel_schedule"] = panel_leg
         if c4 is not None:
             out["config4"] = c4
             if not c4.get("parity", {}).get("ok", True):
@@ -893,9 +937,10 @@ def main():
                                  "MeanITE, L=1, 8192 posterior samples per step"),
                 "c2_literal": run_config(gp, synth, np, torch, dev, local_rank, 1024, 4, 1, 1000, 1, False, False, 5, 1,
                                          "BASELINE configs[1] AS STATED: Synthetic N=1024 D=4 nU=1 continuous treatment, "
-                                         "1k posterior samples = ONE gpslc_predict_dev call per step (S = 1000: one chunk, "
-                                         "a chain of dependent launches with nothing else in flight), fp64, unit A with "
-                                         "MeanITE, L=1; kernel launches per call: profiles/r06_c2_literal_kernel_stats.md"),
+                                         "1k posterior samples = ONE gpslc_predict_dev call per step (S = 1000: one chunk — "
+                                         "Gram build, ONE persistent factorisation launch, MeanITE pass, epilogue — with nothing "
+                                         "else in flight), fp64, unit A with MeanITE, L=1; kernel launches per call: "
+                                         "profiles/r06_c2_literal_kernel_stats.md"),
                 "c3_literal": run_config(gp, synth, np, torch, dev, local_rank, 4096, 8, 2, 5000, 1, False, False, 1, 1,
                                          "BASELINE configs[2] AS STATED: Synthetic N=4096 D=8 nU=2, 5k posterior samples = ONE "
                                          "gpslc_predict_dev call per step (S = 5000: five internal chunks of <= 1,024 matrices), "

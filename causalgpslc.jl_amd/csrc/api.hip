@@ -137,9 +137,10 @@ struct gpslc_ctx {
     std::vector<TaskList> task_lists;
     unsigned long long task_clock = 0;
     bool task_used = false;
-    int task_min_nt = 2, task_max_nt = 24;   // tile counts in this range take the persistent launch (128 < N <= 3072: with
-                                            // groups of 32 it wins at every tile count the descriptor can hold — N = 256 +3 %, 384 +6 %, 1280 / 1536
-                                            // +4 %, 2048 .. 3072 +1..1.7 % against panel 8 + trailing updates, profiles/r06_ab_experiments.md §1d)
+    int task_min_nt = 2, task_max_nt = TASK_MAX_NT;   // tile counts in this range take the persistent launch (128 < N <= 4096: with
+                                            // groups of 32 it wins at every tile count the descriptor can hold — N = 256 +1..3 %, 384 +6 %, 512 +10 %,
+                                            // 1024 +6 %, 1536 +4 %, 2048 +2.4 %, 3072 +1.8 %, 4096 +1.0..1.3 % against panels of 8 + trailing
+                                            // updates, profiles/r06_ab_experiments.md §1d)
     int task_min_batch = 256;      // ... when the chunk holds at least this many matrices: a persistent launch over few
                                    // matrices is a chain of hand-offs (N = 1024: 2.1 ms for 8 matrices against 1.5 ms with one
                                    // launch per column; even at 256, profiles/r06_ab_experiments.md §1)

@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
             const unsigned d = s_next;
             if (d != TASK_NONE) {
                 const int nt = a.nt;
-                const int b = (int)(d & 0x3FFFF), k = (int)((d >> 20) & 31), i = (int)((d >> 25) & 31), rows = (int)((d >> 18) & 3) + 1;
+                const int b = TASK_B(d), k = TASK_K(d), i = TASK_I(d), rows = TASK_ROWS(d);
                 const int* prog = a.sync + TASK_SYNC_HDR + (long long)b * TASK_SYNC_STRIDE;
                 if ((d >> 30) == 3) {               // back-substitution: the whole factor and the solved augmented row
                     task_wait(prog, nt, tmo);
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
         __syncthreads();
         const unsigned d = s_desc;
         if (d == TASK_NONE) break;
-        const int b = (int)(d & 0x3FFFF), k = (int)((d >> 20) & 31), i = (int)((d >> 25) & 31), rows = (int)((d >> 18) & 3) + 1;
+        const int b = TASK_B(d), k = TASK_K(d), i = TASK_I(d), rows = TASK_ROWS(d);
         const bool is_back = (d >> 30) == 3;
         const bool is_diag = (d >> 30) == 1;
         const bool with_aug = (d >> 30) == 2;       // strip(k + 1, k) also carries the augmented tile (nt, k)

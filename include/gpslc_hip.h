@@ -77,8 +77,8 @@ int gpslc_set_tuning(gpslc_ctx* ctx, int32_t max_batch, int32_t panel_tiles, int
  * diagonal-tile, strip and back-substitution tasks of many matrices in flight at once, dependencies through per-matrix
  * progress words, instead of one launch per tile column.  Every output is bit-identical either way.
  * min_tiles: <= 0 = keep (default 2: N > 128); max_tiles: 0 = always one launch per column, negative = keep (default and
- * limit 24: N <= 3072 — beyond one panel of gpslc_set_tuning's panel_tiles, when that was given, the panel schedule is kept:
- * left-looking panels of per-column launches + one trailing update per panel); min_matrices: <= 0 = keep (default 256: a persistent launch
+ * limit 32: N <= 4096 — beyond that, and beyond one panel of gpslc_set_tuning's panel_tiles when that was given, the panel
+ * schedule is kept: left-looking panels of per-column launches + one trailing update per panel); min_matrices: <= 0 = keep (default 256: a persistent launch
  * over a few matrices is a chain of hand-offs — the single scores of an MH step keep the per-column launches); group:
  * matrices per group of the task order, <= 0 = keep (default 32).  Returns 0, or minus the number of the offending argument. */
 int gpslc_set_task_schedule(gpslc_ctx* ctx, int32_t min_tiles, int32_t max_tiles, int32_t min_matrices, int32_t group);

@@ -40,16 +40,16 @@ def test_task_launch_equals_the_per_column_schedule_bit_for_bit(gp, n, S, L):
         _same(x, y)
 
 
-@pytest.mark.parametrize("n,S,L", [(1100, 5, 2), (1536, 3, 1), (2048, 9, 1), (2500, 2, 20), (3072, 3, 1)])
+@pytest.mark.parametrize("n,S,L", [(1100, 5, 2), (1536, 3, 1), (2048, 9, 1), (2500, 2, 20), (3072, 3, 1), (3500, 2, 1), (4096, 9, 3)])
 def test_task_launch_as_one_panel_beyond_eight_tiles(gp, n, S, L):
-    """nt = 9, 12, 16, 20, 24 (the descriptor's limit): with the default panel width the persistent launch factorises the whole
+    """nt = 9, 12, 16, 20, 24, 28, 32 (the descriptor's limit): with the default panel width the persistent launch factorises the whole
     matrix as ONE left-looking panel; the per-column schedule it is compared with runs panels of 8 + trailing updates — different
     launches, the same MFMA chain per tile (ascending k): bit-identical.  A panel width given through gpslc_set_tuning keeps the
     panel schedule beyond it."""
     c = cases.make_case(n, "UX", False, S=S, seed=n + S)
     doT = np.linspace(-0.5, 0.7, L)
     out = []
-    for tiles, panel in ((24, 0), (0, 0), (24, 8)):
+    for tiles, panel in ((32, 0), (0, 0), (32, 8)):
         g = cases.gpslc_object(gp, c)
         g._ctx = gp.Context(g.getN(), g.getNX(), g.getNU(), profile=True)      # HIP-event records: which schedule really ran
         g._ctx.set_data(g.X, g.T, g.Y)
@@ -116,8 +116,8 @@ def test_set_task_schedule_arguments(gp):
     c = cases.make_case(24, "UX", False, S=2, seed=2)
     g = cases.gpslc_object(gp, c)
     lib, h = g.ctx().lib, g.ctx().h
-    assert lib.gpslc_set_task_schedule(h, 25, 8, 0, 0) == -2
-    assert lib.gpslc_set_task_schedule(h, 2, 25, 0, 0) == -3
+    assert lib.gpslc_set_task_schedule(h, 33, 8, 0, 0) == -2
+    assert lib.gpslc_set_task_schedule(h, 2, 33, 0, 0) == -3
     assert lib.gpslc_set_task_schedule(h, 2, 8, 1, 5000) == -5
     assert lib.gpslc_set_task_schedule(h, 0, -1, 0, 0) == 0
     assert lib.gpslc_set_task_schedule(None, 2, 8, 1, 8) == -1

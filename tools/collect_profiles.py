@@ -21,7 +21,7 @@ def blob_sha(path):
 
 
 sha = blob_sha(os.path.join(ROOT, "causalgpslc.jl_amd", "csrc", "k_tilegemm.hip"))
-names = {"kernel_stats.md": f"{rnd}_bench_kernel_stats.md", "kernel_stats_unit_b.md": f"{rnd}_unit_b_kernel_stats.md",
+names = {"pmc_potrf_tasks.md": f"{rnd}_pmc_potrf_tasks.md", "kernel_stats.md": f"{rnd}_bench_kernel_stats.md", "kernel_stats_panel_schedule.md": f"{rnd}_bench_kernel_stats_panel_schedule.md", "kernel_stats_unit_b.md": f"{rnd}_unit_b_kernel_stats.md",
          "pmc_tile_gemm.md": f"{rnd}_pmc_tile_gemm.md", "pmc_fused.md": f"{rnd}_pmc_fused_in_panel.md",
          "pmc_draws.md": f"{rnd}_pmc_draws.md", "kernel_stats_c2.md": f"{rnd}_n1024_kernel_stats.md",
          "pmc_gram.md": f"{rnd}_pmc_gram.md", "pmc_ite_mean.md": f"{rnd}_pmc_ite_mean.md",
@@ -29,7 +29,7 @@ names = {"kernel_stats.md": f"{rnd}_bench_kernel_stats.md", "kernel_stats_unit_b
 for a, b in names.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
-for a, b in {"pmc_tile_gemm.json": f"{rnd}_pmc_tile_gemm.json", "pmc_fused.json": f"{rnd}_pmc_fused_in_panel.json",
+for a, b in {"pmc_potrf_tasks.json": f"{rnd}_pmc_potrf_tasks.json", "pmc_tile_gemm.json": f"{rnd}_pmc_tile_gemm.json", "pmc_fused.json": f"{rnd}_pmc_fused_in_panel.json",
              "pmc_draws.json": f"{rnd}_pmc_draws.json"}.items():
     if not os.path.exists(os.path.join(src, a)):
         continue

@@ -12,8 +12,8 @@ desc = d[:, 4]
 kind4 = (desc >> np.uint64(30)).astype(int)          # 0 strip, 1 diag, 2 strip + augmented tile, 3 back-substitution
 kind = (kind4 == 1).astype(int)
 isback = kind4 == 3
-k = ((desc >> np.uint64(20)) & np.uint64(31)).astype(int)
-i = ((desc >> np.uint64(25)) & np.uint64(31)).astype(int)
+k = ((desc >> np.uint64(19)) & np.uint64(31)).astype(int)
+i = ((desc >> np.uint64(24)) & np.uint64(63)).astype(int)
 nt = int(i[(kind4 == 0) | (kind4 == 2)].max()) if ((kind4 == 0) | (kind4 == 2)).any() else 0
 kind = np.where(isback, 7, kind)
 t = d[:, :4].astype(np.int64)
