@@ -145,7 +145,9 @@ struct gpslc_ctx {
                                    // matrices is a chain of hand-offs (N = 1024: 2.1 ms for 8 matrices against 1.5 ms with one
                                    // launch per column; even at 256, profiles/r06_ab_experiments.md §1)
     int task_group = 32;           // matrices per group of the task order (see build_task_list)
-    int task_rows = 2;             // consecutive tile rows of a column per strip task
+    int task_rows = 2;             // consecutive tile rows of a column per strip task up to 8 tiles per side (beyond: one — long K
+                                   // loops amortise the task's fetch / acquire / publish by themselves, and finer tasks balance
+                                   // better: N = 1536 .. 4096 +0.6 .. 1.2 %, profiles/r06_ab_experiments.md §1d)
     Arena scratch;                 // call-level buffers (internal MeanITE of a draws-only call, ...)
     PoolArena io;                  // staging of the host-pointer entry points and per-call info words
     // single-launch small-n node scores (k_small.hip): pinned, device-visible host staging (descriptors, inputs,
@@ -506,7 +508,7 @@ void potrf_tasks(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
     static const int g_env = diag_env("GPSLC_TASK_G", 0);
     static const int r_env = diag_env("GPSLC_TASK_ROWS", 0);
     const TaskList& tl = task_list_for(c, nt, back_alpha ? 1 : 0, nb, g_env > 0 ? g_env : c->task_group,
-                                       std::max(1, std::min(4, r_env > 0 ? r_env : c->task_rows)));
+                                       std::max(1, std::min(4, r_env > 0 ? r_env : (nt > 8 ? 1 : c->task_rows))));
     HC(hipMemsetAsync(c->task_sync[slot], 0, ints * sizeof(int), st));
     PotrfTaskArgs a{};
     a.g.A = M; a.g.B = M; a.g.C = M;
