@@ -8,15 +8,15 @@ PART=${2:-a}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-configs"
+B="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-configs --no-panel-leg"
 UB="python3 $GRAFT_REPO_ROOT/tools/bench_unit_b.py 4096 64 1 10"
-C2="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-configs --no-units --n 1024 --d 4 --nu 1 --samples-per-step 8192"
-C2L="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-configs --no-units --n 1024 --d 4 --nu 1 --samples-per-step 1000"
+C2="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-configs --no-units --no-panel-leg --n 1024 --d 4 --nu 1 --samples-per-step 8192"
+C2L="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-config4 --no-configs --no-units --no-panel-leg --n 1024 --d 4 --nu 1 --samples-per-step 1000"
 KS="python3 $GRAFT_REPO_ROOT/tools/kernel_stats_md.py"
 PS="python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py"
 if [ "$PART" = a ]; then
 # (1) unit A: the bench's timed region, per-kernel durations (HIP-event profiling on, as in the driver's run)
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --no-units --no-panel-leg > $OUT/trace.log 2>&1 &&
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --no-units > $OUT/trace.log 2>&1 &&
 # (1b) the same with one launch per tile column (the schedule of rounds 1-5: panels of 8 + trailing updates)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_p -- $B --no-units --task-tiles 0 > $OUT/trace_p.log 2>&1 &&
 # (2) units B and C: 64 (sample, level) units with 10 draws each per call (warm-up call + two full-size calls)
