@@ -106,6 +106,7 @@ constexpr int kProfClasses = 5;
 // factorisation launch (potrf_tasks_kernel); built once per shape and kept (see task_list_for)
 struct TaskList {
     int nt = 0, back = 0, nb = 0, G = 0, rows = 0;
+    bool aug_full = false;
     unsigned* dev = nullptr;
     long long ntasks = 0;
     unsigned long long used = 0;
@@ -420,7 +421,7 @@ TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstri
 // never finds its producer unfinished), and (2) every stretch of the order mixes the latency-bound diagonal tasks of some
 // groups with the MFMA-bound strips of others.  Inside a stage the strips of one matrix are consecutive tickets: they run
 // at the same time on one XCD and share the B panel L(k, 0..k-1) in its L2.
-std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, int rows_per_task, long long* ntasks_out) {
+std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, int rows_per_task, bool aug_full, long long* ntasks_out) {
     std::vector<unsigned> out(TASK_LIST_HDR, 0u);
     static const int merge_diag = diag_env("GPSLC_TASK_MERGE", 1);      // measurement switch: 0 = strip(k + 1, k) as a task of its own
     const int NS = 2 * nt + (back ? 1 : 0);       // back: one more stage, the back-substitution of the finished factor
@@ -442,8 +443,12 @@ std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, int rows_
                     // its descriptor): the next diagonal task waits for exactly those two.  The last column has no strip: its
                     // augmented tile is a task of its own
                     if ((s & 1) == 0) { out.push_back(task_pack(b, k, k, TASK_DIAG, (merge_diag && k + 1 < nt) ? 2 : 1)); continue; }
-                    if (k + 1 < nt) { if (!merge_diag) out.push_back(task_pack(b, k, k + 1, TASK_STRIP_AUG)); }
-                    else out.push_back(task_pack(b, k, nt, TASK_STRIP));
+                    // aug_full (more than 32 right-hand sides): the augmented row is a tile row like the others, strip(nt, k) in
+                    // every column; otherwise its tiles ride with the diagonal tasks and only the last column's is a task of its own
+                    if (k + 1 < nt) {
+                        if (!merge_diag) out.push_back(task_pack(b, k, k + 1, aug_full ? TASK_STRIP : TASK_STRIP_AUG));
+                        if (aug_full) out.push_back(task_pack(b, k, nt, TASK_STRIP));
+                    } else out.push_back(task_pack(b, k, nt, TASK_STRIP));
                     for (int i = k + 2; i < nt; i += rows_per_task)
                         out.push_back(task_pack(b, k, i, TASK_STRIP, std::min(rows_per_task, nt - i)));
                 }
@@ -456,9 +461,9 @@ std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, int rows_
     return out;
 }
 
-const TaskList& task_list_for(gpslc_ctx* c, int nt, int back, int nb, int G, int rows) {
+const TaskList& task_list_for(gpslc_ctx* c, int nt, int back, int nb, int G, int rows, bool aug_full) {
     for (auto& t : c->task_lists)
-        if (t.nt == nt && t.back == back && t.nb == nb && t.G == G && t.rows == rows) { t.used = ++c->task_clock; return t; }
+        if (t.nt == nt && t.back == back && t.nb == nb && t.G == G && t.rows == rows && t.aug_full == aug_full) { t.used = ++c->task_clock; return t; }
     if (c->task_lists.size() >= 8) {       // evict the least recently used shape (nothing of it may still be in flight)
         size_t v = 0;
         for (size_t i = 1; i < c->task_lists.size(); ++i)
@@ -468,8 +473,8 @@ const TaskList& task_list_for(gpslc_ctx* c, int nt, int back, int nb, int G, int
         c->task_lists.erase(c->task_lists.begin() + (long)v);
     }
     TaskList t;
-    t.nt = nt; t.back = back; t.nb = nb; t.G = G; t.rows = rows;
-    std::vector<unsigned> h = build_task_list(nt, back, nb, G, rows, &t.ntasks);
+    t.nt = nt; t.back = back; t.nb = nb; t.G = G; t.rows = rows; t.aug_full = aug_full;
+    std::vector<unsigned> h = build_task_list(nt, back, nb, G, rows, aug_full, &t.ntasks);
     HC(hipMalloc((void**)&t.dev, h.size() * sizeof(unsigned)));
     HC(hipMemcpy(t.dev, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     t.used = ++c->task_clock;
@@ -488,7 +493,7 @@ bool potrf_tasks_ok(const gpslc_ctx* c, int nt, int ntot, int short_rows, bool s
     if (!on || !inv || nt < std::max(2, c->task_min_nt) || nt > std::min(std::min(c->task_max_nt, TASK_MAX_NT), pmax) ||
         nb >= TASK_MAX_BATCH || nb < c->task_min_batch)
         return false;
-    return ntot == nt + 1 && short_rows > 0 && short_rows <= 32 && skip_aug_diag;
+    return ntot == nt + 1 && short_rows > 0 && short_rows <= GP_TS && skip_aug_diag;
 }
 
 // back_alpha (optional, [nb][nt 128]): every matrix's task chain ends with its back-substitution alpha = L^-T z (z = right-hand
@@ -508,7 +513,7 @@ void potrf_tasks(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
     static const int g_env = diag_env("GPSLC_TASK_G", 0);
     static const int r_env = diag_env("GPSLC_TASK_ROWS", 0);
     const TaskList& tl = task_list_for(c, nt, back_alpha ? 1 : 0, nb, g_env > 0 ? g_env : c->task_group,
-                                       std::max(1, std::min(4, r_env > 0 ? r_env : (nt > 8 ? 1 : c->task_rows))));
+                                       std::max(1, std::min(4, r_env > 0 ? r_env : (nt > 8 ? 1 : c->task_rows))), short_rows > 32);
     HC(hipMemsetAsync(c->task_sync[slot], 0, ints * sizeof(int), st));
     PotrfTaskArgs a{};
     a.g.A = M; a.g.B = M; a.g.C = M;
@@ -534,7 +539,7 @@ void potrf_tasks(gpslc_ctx* c, const TRef& M, int nt, int ntot, double* inv, lon
 #endif
     {
         ProfScope ps(c, 4, (Np * Np * Np / 3.0 + (double)a.g.short_rows * Np * Np) * (double)nb, st);
-        launch_potrf_tasks(a, tl.ntasks, (short_rows + 15) / 16, st);
+        launch_potrf_tasks(a, tl.ntasks, short_rows > 32 ? 0 : (short_rows + 15) / 16, st);
     }
     HC(hipGetLastError());
 #ifdef GPSLC_DIAG

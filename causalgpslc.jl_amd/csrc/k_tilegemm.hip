@@ -932,7 +932,8 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
                     }
                 } else {                            // strip(i.., k): inv(L_kk) and tile row k (diag(k)), the tile rows up to column k - 1
                     task_wait(prog, k + 1, tmo);
-                    if (i < nt && k > 0)
+                    // MT == 0: the augmented row (i == nt) is an ordinary tile row whose strips carry their own column update
+                    if ((i < nt || MT == 0) && k > 0)
                         for (int r = 0; r < rows; ++r) task_wait(prog + 1 + i + r, k, tmo);
                 }
                 if (GP_DBG_ON(a)) s_ready = __builtin_amdgcn_s_memtime();       // producers done (before the acquire)
@@ -1009,7 +1010,7 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
                                               lg * LROW + 32 * wave + li, lg * LROW + li, loff, 0, true);
             else
                 for (int r = 0; r < rows; ++r)
-                    strip_item<FUSE_WD, (MT > 0), WT>(gl, b, i + r, k, /*no_update=*/i >= a.nt, 8 * k, smem, smem + 2 * OPER_LDS, tid,
+                    strip_item<FUSE_WD, (MT > 0), WT>(gl, b, i + r, k, /*no_update=*/MT > 0 && i >= a.nt, 8 * k, smem, smem + 2 * OPER_LDS, tid,
                                                   lane, wave, li, lg, lg * LROW + 32 * wave + li, lg * LROW + li, loff, 0,
                                                   with_aug && r == 0);
         }
@@ -1030,7 +1031,7 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
                     __hip_atomic_store(prog, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (diag_then_strip) {
                         __hip_atomic_store(prog + 2 + k, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(prog + 1 + a.nt, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (MT > 0) __hip_atomic_store(prog + 1 + a.nt, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 } else
                     for (int r = 0; r < rows; ++r)
@@ -1061,7 +1062,9 @@ static void launch_potrf_tasks_t(const PotrfTaskArgs& a, unsigned grid, hipStrea
     hipLaunchKernelGGL((potrf_tasks_kernel<MT, WT>), dim3(grid), dim3(256), bytes, st, a);
 }
 
-// mt: 16-row blocks (1 or 2) of the augmented right-hand-side row that ride with the diagonal tasks
+// mt: 16-row blocks (1 or 2) of the augmented right-hand-side row that ride with the diagonal tasks; 0: more than 32 right-hand
+// sides (a level sweep: src/prediction.jl:24-33 runs ~100 levels per posterior sample) — the augmented row is an ordinary tile
+// row of the task list, strip(nt, k) with its own column update over the live rows, as in the per-column launches
 void launch_potrf_tasks(const PotrfTaskArgs& a, long long ntasks, int mt, hipStream_t st) {
     if (ntasks <= 0) return;
     int slots = 2 * device_cus();
@@ -1071,12 +1074,14 @@ void launch_potrf_tasks(const PotrfTaskArgs& a, long long ntasks, int mt, hipStr
     const unsigned grid = (unsigned)(ntasks < slots ? ntasks : slots);
 #ifdef GPSLC_DIAG
     if (a.fence_mode & 2) {      // measurement build, GPSLC_TASK_FENCE bit 1: plain / nt payload stores + an agent-scope release fence
-        if (mt <= 1) launch_potrf_tasks_t<1, false>(a, grid, st);
+        if (mt == 0) launch_potrf_tasks_t<0, false>(a, grid, st);
+        else if (mt <= 1) launch_potrf_tasks_t<1, false>(a, grid, st);
         else launch_potrf_tasks_t<2, false>(a, grid, st);
         return;
     }
 #endif
-    if (mt <= 1) launch_potrf_tasks_t<1, true>(a, grid, st);
+    if (mt == 0) launch_potrf_tasks_t<0, true>(a, grid, st);
+    else if (mt <= 1) launch_potrf_tasks_t<1, true>(a, grid, st);
     else launch_potrf_tasks_t<2, true>(a, grid, st);
 }
 

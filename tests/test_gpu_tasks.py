@@ -19,7 +19,7 @@ def _same(a, b):
 
 def _both(gp, c, doT, max_batch=0, group=0, **kw):
     out = []
-    for tiles in (8, 0):                       # persistent launch (from 2 tiles per side and ONE matrix on), one launch per column
+    for tiles in (32, 0):                      # persistent launch (from 2 tiles per side and ONE matrix on), one launch per column
         g = cases.gpslc_object(gp, c)
         g.ctx().set_task_schedule(2, tiles, 1, group)
         if max_batch:
@@ -63,6 +63,19 @@ def test_task_launch_as_one_panel_beyond_eight_tiles(gp, n, S, L):
     for other in out[1:]:
         for x, y in zip(out[0], other):
             _same(x, y)
+
+
+@pytest.mark.parametrize("n,S,L", [(640, 5, 33), (1024, 9, 64), (1000, 3, 101), (300, 11, 126), (2048, 3, 40), (4096, 2, 64)])
+def test_task_launch_with_a_level_sweep_of_more_than_32_right_hand_sides(gp, n, S, L):
+    """More than 32 right-hand sides (the sweep of src/prediction.jl:24-33 runs ~100 levels per posterior sample): the augmented
+    row no longer rides with the diagonal tasks — it is an ordinary tile row of the task list, strip(nt, k) with its own column
+    update over the live rows, exactly the work item the per-column launches give it: bit-identical, MeanITE of every level
+    included (the back-substitution task reads right-hand side 0 of that row)."""
+    c = cases.make_case(n, "UX", False, S=S, seed=n + L)
+    doT = np.linspace(-0.8, 0.9, L)
+    a, b = _both(gp, c, doT)
+    for x, y in zip(a, b):
+        _same(x, y)
 
 
 @pytest.mark.parametrize("group", [1, 3, 64])
