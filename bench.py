@@ -716,6 +716,10 @@ def main():
             panel_leg["fused_in_panel_kernel"] = {"kernel": kname1, "achieved": pfl1 / (pms1 * 1e-3) / 1e12,
                                                   "frac": pfl1 / (pms1 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "launches": int(pl1),
                                                   "avg_launch_ms": pms1 / pl1, "share_of_step_time": pms1 * 1e-3 / dtp}
+        if "trailing_update_kernel" in panel_leg:
+            ptr_, pnote = pmc_traffic((n, D, K, L, Sr) == (4096, 8, 2, 1, 1024) and a.max_batch == 0 and a.panel == 0, "pmc_tile_gemm")
+            panel_leg["trailing_update_kernel"]["traffic"] = ptr_
+            panel_leg["trailing_update_kernel"]["traffic_note"] = pnote
         ctx.set_task_schedule(a.task_min_tiles, 32, a.task_min_matrices, a.task_group)
 
     # ---- BASELINE configs[3]: the same posterior samples x 64 intervention levels (the sweep of

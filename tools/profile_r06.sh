@@ -45,11 +45,16 @@ for k in potrf_tasks_kernel gram_kernel ite_mean_kernel rhs_tiles_kernel rhs_pre
 rm -rf $OUT/c2pmc $OUT/trace $OUT/trace_p $OUT/trace_b $OUT/trace_c2 $OUT/trace_c2l
 head -22 $OUT/kernel_stats.md; head -8 $OUT/kernel_stats_c2_literal.md
 else
+rm -f $OUT/pmc_*.json $OUT/pmc_*.md      # a kernel without rows must not leave an older summary behind for the collector
 # (3) PMC passes, one counter group per run, unit A
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmcA/pmc_fetch -- $B --no-units --no-profile > $OUT/pmc_fetch.log 2>&1 &&
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmcA/pmc_write -- $B --no-units --no-profile > $OUT/pmc_write.log 2>&1 &&
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmcA/pmc_sq -- $B --no-units --no-profile > $OUT/pmc_sq.log 2>&1 &&
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum --output-format csv -d $OUT/pmcA/pmc_ea -- $B --no-units --no-profile > $OUT/pmc_ea.log 2>&1 &&
+# (3a) the panel schedule of rounds 1-5 (--task-tiles 0: what roofline.panel_schedule times): trailing-update and strip kernels
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmcP/pmc_fetch -- $B --no-units --no-profile --task-tiles 0 > $OUT/pmcP_fetch.log 2>&1 &&
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmcP/pmc_write -- $B --no-units --no-profile --task-tiles 0 > $OUT/pmcP_write.log 2>&1 &&
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmcP/pmc_sq -- $B --no-units --no-profile --task-tiles 0 > $OUT/pmcP_sq.log 2>&1 &&
 # (3b) VALU issue counters (the two fp64-VALU kernels of unit A: Gram build, MeanITE pass)
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmcA/pmc_valu -- $B --no-units --no-profile > $OUT/pmc_valu.log 2>&1 &&
 # (4) PMC passes for the draws kernel (unit C): bytes of L_c actually fetched per launch
@@ -59,12 +64,12 @@ cd $GRAFT_REPO_ROOT
 # unit A at N = 4096 is ONE persistent launch of tile tasks since the second half of round 6 (the panel leg of the bench line still
 # runs the trailing-update and strip kernels: their rows are that leg's launches)
 $PS $OUT/pmcA "potrf_tasks_kernel" $OUT/pmc_potrf_tasks.json > $OUT/pmc_potrf_tasks.md
-$PS $OUT/pmcA "tile_gemm_nt_kernel<1, 0>" $OUT/pmc_tile_gemm.json > $OUT/pmc_tile_gemm.md
-$PS $OUT/pmcA "tile_fused_strip_kernel" $OUT/pmc_fused.json > $OUT/pmc_fused.md
+$PS $OUT/pmcP "tile_gemm_nt_kernel<1, 0>" $OUT/pmc_tile_gemm.json > $OUT/pmc_tile_gemm.md
+$PS $OUT/pmcP "tile_fused_strip_kernel" $OUT/pmc_fused.json > $OUT/pmc_fused.md
 $PS $OUT/pmcA "gram_kernel" $OUT/pmc_gram.json > $OUT/pmc_gram.md
 $PS $OUT/pmcA "ite_mean_kernel" $OUT/pmc_ite_mean.json > $OUT/pmc_ite_mean.md
 $PS $OUT/pmcB "draws_stream_kernel" $OUT/pmc_draws.json > $OUT/pmc_draws.md
 $PS $OUT/pmcB "draws_zstage_kernel" $OUT/pmc_draws_zstage.json > $OUT/pmc_draws_zstage.md
-rm -rf $OUT/pmcA $OUT/pmcB
+rm -rf $OUT/pmcA $OUT/pmcB $OUT/pmcP
 tail -4 $OUT/pmc_potrf_tasks.md; tail -4 $OUT/pmc_tile_gemm.md; tail -6 $OUT/pmc_draws.md
 fi
