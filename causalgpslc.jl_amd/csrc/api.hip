@@ -413,54 +413,7 @@ const unsigned short* tri_order(gpslc_ctx* c, int m) {
 TRef lower_ref(double* base, long long bstride) { return TRef{base, bstride, 0, 0, 0, 0}; }
 TRef rect_ref(double* base, long long bstride, int ld) { return TRef{base, bstride, 1, 0, 0, ld}; }
 
-// ---- the persistent factorisation launch (potrf_tasks_kernel, k_tilegemm.hip) -------------------------------------------
-// Task order of one queue (= one XCD's contiguous run of matrices).  Stages of a matrix: s = 2k: diag(k), s = 2k + 1: the
-// strips of column k.  Matrices are taken in groups of G; step t of the order holds stage s of group t - s for every s — a
-// skewed wavefront, so that (1) every task follows its producers (stage s - 1 of the same group sits one whole step
-// earlier: ~ G * (nt + nt (nt + 1) / 2) tickets, several rounds of the XCD's 64 workgroup slots — a consumer practically
-// never finds its producer unfinished), and (2) every stretch of the order mixes the latency-bound diagonal tasks of some
-// groups with the MFMA-bound strips of others.  Inside a stage the strips of one matrix are consecutive tickets: they run
-// at the same time on one XCD and share the B panel L(k, 0..k-1) in its L2.
-std::vector<unsigned> build_task_list(int nt, int back, int nb, int G, int rows_per_task, bool aug_full, long long* ntasks_out) {
-    std::vector<unsigned> out(TASK_LIST_HDR, 0u);
-    static const int merge_diag = diag_env("GPSLC_TASK_MERGE", 1);      // measurement switch: 0 = strip(k + 1, k) as a task of its own
-    const int NS = 2 * nt + (back ? 1 : 0);       // back: one more stage, the back-substitution of the finished factor
-    long long total = 0;
-    const int wq = nb >> 3, wrm = nb & 7;
-    for (int x = 0; x < 8; ++x) {
-        const int x0 = x * wq + std::min(x, wrm), xc = wq + (x < wrm ? 1 : 0);
-        const size_t first = out.size() - TASK_LIST_HDR;
-        const int NG = (xc + G - 1) / G;
-        for (int t = 0; t < NG + NS - 1; ++t)
-            for (int s = 0; s < NS; ++s) {
-                const int g = t - s;
-                if (g < 0 || g >= NG) continue;
-                const int k = s >> 1;
-                for (int j = g * G; j < std::min(xc, (g + 1) * G); ++j) {
-                    const int b = x0 + j;
-                    if (s == 2 * nt) { out.push_back(task_pack(b, 0, 0, TASK_BACK)); continue; }
-                    // a diagonal task goes on with the strip of tile row k + 1 and the augmented tile of its column (rows = 2 in
-                    // its descriptor): the next diagonal task waits for exactly those two.  The last column has no strip: its
-                    // augmented tile is a task of its own
-                    if ((s & 1) == 0) { out.push_back(task_pack(b, k, k, TASK_DIAG, (merge_diag && k + 1 < nt) ? 2 : 1)); continue; }
-                    // aug_full (more than 32 right-hand sides): the augmented row is a tile row like the others, strip(nt, k) in
-                    // every column; otherwise its tiles ride with the diagonal tasks and only the last column's is a task of its own
-                    if (k + 1 < nt) {
-                        if (!merge_diag) out.push_back(task_pack(b, k, k + 1, aug_full ? TASK_STRIP : TASK_STRIP_AUG));
-                        if (aug_full) out.push_back(task_pack(b, k, nt, TASK_STRIP));
-                    } else out.push_back(task_pack(b, k, nt, TASK_STRIP));
-                    for (int i = k + 2; i < nt; i += rows_per_task)
-                        out.push_back(task_pack(b, k, i, TASK_STRIP, std::min(rows_per_task, nt - i)));
-                }
-            }
-        out[x] = (unsigned)first;
-        out[8 + x] = (unsigned)(out.size() - TASK_LIST_HDR - first);
-        total += out[8 + x];
-    }
-    *ntasks_out = total;
-    return out;
-}
-
+// ---- the persistent factorisation launch (potrf_tasks_kernel, k_tilegemm.hip): task order = build_task_list, task_list.h ----
 const TaskList& task_list_for(gpslc_ctx* c, int nt, int back, int nb, int G, int rows, bool aug_full) {
     for (auto& t : c->task_lists)
         if (t.nt == nt && t.back == back && t.nb == nb && t.G == G && t.rows == rows && t.aug_full == aug_full) { t.used = ++c->task_clock; return t; }
@@ -474,7 +427,8 @@ const TaskList& task_list_for(gpslc_ctx* c, int nt, int back, int nb, int G, int
     }
     TaskList t;
     t.nt = nt; t.back = back; t.nb = nb; t.G = G; t.rows = rows; t.aug_full = aug_full;
-    std::vector<unsigned> h = build_task_list(nt, back, nb, G, rows, aug_full, &t.ntasks);
+    static const int merge_diag = diag_env("GPSLC_TASK_MERGE", 1);      // measurement switch: 0 = strip(k + 1, k) as a task of its own
+    std::vector<unsigned> h = build_task_list(nt, back, nb, G, rows, aug_full, &t.ntasks, merge_diag);
     HC(hipMalloc((void**)&t.dev, h.size() * sizeof(unsigned)));
     HC(hipMemcpy(t.dev, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     t.used = ++c->task_clock;

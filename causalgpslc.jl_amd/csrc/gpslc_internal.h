@@ -142,23 +142,7 @@ struct GramArgs {
 // 7 - k strips of a column share the B panel in one L2) in an order in which every task follows its producers; progress
 // words per matrix in global memory carry the dependencies between workgroups (agent-scope release / acquire).
 // ---------------------------------------------------------------------------------------
-#define TASK_NONE 0xFFFFFFFFu
-#define TASK_LIST_HDR 32          // words: [0, 8) first descriptor of queue x, [8, 16) descriptors of queue x
-#define TASK_SYNC_HDR 32          // ints: [0, 8) ticket heads, [8] time-out word, [9] tasks finished
-#define TASK_SYNC_STRIDE 40       // ints per matrix: [0] diagonal tiles finished, [1 + i] finished tiles of tile row i (i <= nt)
-#define TASK_MAX_NT 32
-// descriptor: bits 0..16 batch element, 17..18 (strips) number of consecutive tile rows of the column the task covers minus 1,
-// 19..23 column k, 24..29 (first) tile row i (up to nt = 32: the augmented tile row), 30..31 kind: 0 strip(i.., k), 1 diag(k), 2 strip(k + 1, k) that also applies the
-// panel product to the augmented tile (nt, k), 3 the back-substitution of the matrix
-enum { TASK_STRIP = 0, TASK_DIAG = 1, TASK_STRIP_AUG = 2, TASK_BACK = 3 };
-#define TASK_MAX_BATCH (1 << 17)
-#define TASK_B(d) ((int)((d) & 0x1FFFF))
-#define TASK_ROWS(d) ((int)(((d) >> 17) & 3) + 1)
-#define TASK_K(d) ((int)(((d) >> 19) & 31))
-#define TASK_I(d) ((int)(((d) >> 24) & 63))
-__host__ __device__ inline unsigned task_pack(int b, int k, int i, int kind, int rows = 1) {
-    return (unsigned)b | ((unsigned)(rows - 1) << 17) | ((unsigned)k << 19) | ((unsigned)i << 24) | ((unsigned)kind << 30);
-}
+#include "task_list.h"     // descriptor layout + the host-built task order (plain C++: tests/c/task_list_test.cpp exercises it on the CPU)
 struct PotrfTaskArgs {
     GemmArgs g;             // A = B = C = the tile matrix, F = the inverted diagonal blocks, k0 = 0, short_row0 = nt, short_rows,
                             // sym = 3 with an augmented row riding along, info / info_base, nbatch
