@@ -41,11 +41,15 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define GP_DIAG_SKIP(g) ((g).diag_skip)
 #define GP_FENCE_MODE(a) ((a).fence_mode & 1)
 #define GP_TASK_PRIO(a) (((a).fence_mode >> 4) & 3)      // GPSLC_TASK_FENCE bits 4..5: priority of the diagonal tasks
+// bit 6: diag(1) of matrix 0 never publishes its progress — a deliberately broken hand-off, for the test of the time-out word
+// (tests/test_gpu_tasks.py: the launch must drain and the call must come back with GPSLC_ERR_INTERNAL, not hang)
+#define GP_TASK_WITHHOLD(a, b, is_diag, k) ((((a).fence_mode >> 6) & 1) && (b) == 0 && (is_diag) && (k) == 1)
 #else
 #define GP_DBG_ON(g) false
 #define GP_DIAG_SKIP(g) 0
 #define GP_FENCE_MODE(a) 0
 #define GP_TASK_PRIO(a) 3
+#define GP_TASK_WITHHOLD(a, b, is_diag, k) false
 #endif
 
 // The trailing-update kernel raises its waves' issue priority around the 64 MFMAs of a slab (s_setprio 1) and drops it for
@@ -1024,7 +1028,7 @@ __global__ __launch_bounds__(256, 2) void potrf_tasks_kernel(PotrfTaskArgs a) {
             const bool hit = tnext < lenn;
             if (hit) dn = a.list[TASK_LIST_HDR + a.list[qn] + tnext];
             int* prog = a.sync + TASK_SYNC_HDR + (long long)b * TASK_SYNC_STRIDE;
-            if (!is_back) {
+            if (!is_back && !GP_TASK_WITHHOLD(a, b, is_diag, k)) {
                 if (GP_FENCE_MODE(a) == 0 && !WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (is_diag) {

@@ -134,3 +134,39 @@ def test_set_task_schedule_arguments(gp):
     assert lib.gpslc_set_task_schedule(h, 2, 8, 1, 5000) == -5
     assert lib.gpslc_set_task_schedule(h, 0, -1, 0, 0) == 0
     assert lib.gpslc_set_task_schedule(None, 2, 8, 1, 8) == -1
+
+
+def test_a_broken_hand_off_times_out_instead_of_hanging(tmp_path):
+    """The launch's safety net: a consumer's poll is bounded, the first one to exceed its bound sets the time-out word, every
+    workgroup stops waiting, the launch drains and the call returns GPSLC_ERR_INTERNAL — never a hung GPU.  Exercised with the
+    measurement build (GPSLC_TASK_FENCE bit 6: diag(1) of matrix 0 never publishes its progress) in a fresh process, because that
+    build reads its switches once; the production library has no such switch (it never reads the environment)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "causalgpslc.jl_amd", "csrc", "libgpslc_hip_diag.so")
+    if not os.path.exists(diag):
+        pytest.skip("measurement build not present (make -C causalgpslc.jl_amd/csrc diag)")
+    code = (
+        "import sys, time, numpy as np\n"
+        f"sys.path[:0] = [{root!r}, {os.path.join(root, 'tests')!r}, {os.path.join(root, 'oracle')!r}]\n"
+        "import causalgpslc_jl_amd as gp, cases\n"
+        "gp._lib.LIB_PATH = gp._lib.LIB_PATH.replace('libgpslc_hip.so', 'libgpslc_hip_diag.so')\n"
+        "c = cases.make_case(520, 'UX', False, S=9, seed=3)\n"
+        "g = cases.gpslc_object(gp, c)\n"
+        "g.ctx().set_task_schedule(2, 32, 1, 0)\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    gp.predict(g, [0.2], want_mean_ite=True)\n"
+        "    print('NO ERROR')\n"
+        "except gp.GPSLCError as e:\n"
+        "    print('ERROR', e.status, str(e))\n"
+        "print('seconds', round(time.time() - t0, 2))\n")
+    env = dict(os.environ, GPSLC_TASK_FENCE=str(0x30 | 0x40))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    out = r.stdout
+    assert r.returncode == 0, (out, r.stderr[-2000:])
+    assert "ERROR" in out and "timed out" in out, out
+    secs = float(out.strip().splitlines()[-1].split()[1])
+    assert secs < 60, out
