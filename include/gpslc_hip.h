@@ -67,7 +67,10 @@ int gpslc_set_data(gpslc_ctx* ctx, const double* X, const double* T, const doubl
 int gpslc_set_data_dev(gpslc_ctx* ctx, const double* X, const double* T, const double* Y);
 
 /* Tuning knobs (0 = keep default): max posterior samples factorised concurrently, tile-panel
- * width of the blocked Cholesky, number of HIP streams chunks are spread over. */
+ * width of the blocked Cholesky, number of HIP streams chunks are spread over.  A panel width given here
+ * also bounds the persistent task launch (gpslc_set_task_schedule below): matrices of more tiles per side
+ * than panel_tiles then take the panel schedule (left-looking panels + trailing updates) instead of
+ * being factorised as ONE panel of tasks. */
 int gpslc_set_tuning(gpslc_ctx* ctx, int32_t max_batch, int32_t panel_tiles, int32_t n_streams);
 
 /* Schedule of the factorisation of A at small tile counts (round 6; no reference counterpart: the reference factorises
